@@ -1,0 +1,151 @@
+/*
+ * excenv.h — C ABI of the MI355X-native batched ODE stepper behind
+ * exciting-environments' vmap_step / vmap_sim_ahead hot path.
+ *
+ * The reference has no FFI of its own (it is pure Python on JAX/diffrax); the
+ * boundary it exposes is the object returned by EnvironmentRegistry.X.make()
+ * (reference exciting_environments/registration.py:21-32). Each entry point below
+ * names the reference method whose arithmetic it replaces. All pointers are raw
+ * device pointers (hipMalloc'ed / torch CUDA storage), sizes are plain integers,
+ * `stream` is a hipStream_t passed as void*. No function throws, allocates device
+ * memory, or synchronises the device: they only enqueue kernels on `stream`
+ * (hipGraph-capturable). Return value: 0 on success, a negative EXCENV_E* code
+ * otherwise; excenv_last_error() gives the per-thread message.
+ *
+ * Data layout (struct-of-arrays): every state field / per-env parameter is its
+ * own contiguous [B] array. Trajectories come in two layouts:
+ *   EXCENV_LAYOUT_ENV_MAJOR  : element (b,k,c) at ((b*K)+k)*C + c  — the reference's
+ *                              row-major jnp arrays actions[B,K,A], observations[B,K+1,O],
+ *                              state leaves [B,K+1] (core_env.py:571-616).
+ *   EXCENV_LAYOUT_LANE_MAJOR : element (b,k,c) at ((k*C)+c)*B + b  — one lane per env,
+ *                              lane-adjacent envs address-adjacent (fully coalesced).
+ */
+#ifndef EXCENV_H
+#define EXCENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXCENV_ABI_VERSION 1
+
+/* Environment ids. Field orders follow the reference dataclasses. */
+typedef enum {
+  EXCENV_PENDULUM = 0,           /* pendulum/pendulum_env.py:116-142   S=(theta,omega) A=(torque) P=(g,l,m) */
+  EXCENV_MASS_SPRING_DAMPER = 1, /* mass_spring_damper_env.py:113-139  S=(deflection,velocity) A=(force) P=(d,k,m) */
+  EXCENV_CART_POLE = 2,          /* cart_pole_env.py:126-157           S=(deflection,velocity,theta,omega) A=(force) P=(mu_p,mu_c,l,m_p,m_c,g) */
+  EXCENV_ACROBOT = 3,            /* acrobot_env.py:135-169             S=(theta_1,theta_2,omega_1,omega_2) A=(torque) P=(g,l_1,l_2,m_1,m_2,l_c1,l_c2,I_1,I_2) */
+  EXCENV_FLUID_TANK = 4,         /* fluid_tank_env.py:70-95            S=(height) A=(inflow) P=(base_area,orifice_area,c_d,g) */
+  EXCENV_PMSM = 5,               /* pmsm/pmsm_env.py:269-305 (linear dq model) S=(u_d_buffer,u_q_buffer,epsilon,i_d,i_q,torque,omega_el)
+                                    A=(u_d,u_q) P=(p,r_s,l_d,l_q,psi_p,u_dc,deadtime) O=(i_d,i_q,omega_el,torque,cos eps,sin eps,u_d_buffer,u_q_buffer) */
+  EXCENV_NUM_ENVS = 6
+} excenv_env_t;
+
+/* Fixed-step explicit solvers (stand-ins for diffrax.Euler / diffrax.Tsit5 passed as
+ * `solver=`; RK4 is a build-side extension). */
+typedef enum { EXCENV_EULER = 0, EXCENV_RK4 = 1, EXCENV_TSIT5 = 2, EXCENV_NUM_SOLVERS = 3 } excenv_solver_t;
+
+typedef enum { EXCENV_F32 = 0, EXCENV_F64 = 1 } excenv_dtype_t;
+
+typedef enum { EXCENV_LAYOUT_ENV_MAJOR = 0, EXCENV_LAYOUT_LANE_MAJOR = 1 } excenv_layout_t;
+
+/* Trajectory semantics of excenv_sim_ahead.
+ *   EXCENV_SEM_STEP  : the K steps are exactly K applications of excenv_step (post-processing —
+ *                      angle wrap, tank clip, PMSM angle prediction — acts on the carried state).
+ *                      This is the property the reference tests (tests/envs/test_core_functions.py:134-155).
+ *   EXCENV_SEM_AHEAD : structure of the reference's _ode_solver_simulate_ahead (e.g.
+ *                      pendulum_env.py:196-259, fluid_tank_env.py:156-216, pmsm_env.py:709-801): the raw
+ *                      ODE state is carried un-wrapped / un-clipped, post-processing is applied to the SAVED
+ *                      rows only, PMSM clips all actions with the predicted angle eps0 + k*tau*omega, and RK
+ *                      stages with c_i == 1 read action k+1 (core_env.py:435-439). Step size is exactly
+ *                      obs_stepsize and the action index is exactly floor(step / substeps) (diffrax's
+ *                      accumulated-time rounding is deliberately not reproduced).
+ */
+typedef enum { EXCENV_SEM_STEP = 0, EXCENV_SEM_AHEAD = 1 } excenv_semantics_t;
+
+#define EXCENV_MAX_STATE 8
+#define EXCENV_MAX_ACTION 2
+#define EXCENV_MAX_STATIC 9
+#define EXCENV_MAX_CONTROL 8
+
+/* A property leaf is either broadcast (per_env == NULL, `value` used) or batched
+ * (per_env -> [B] array of the working dtype): reference core_env.py:253-277. */
+typedef struct {
+  double value;
+  const void* per_env;
+} excenv_param_t;
+
+/* EnvProperties (core_env.py:245-251): static params in the field order listed at the env id,
+ * min/max of physical_normalizations per state field and of action_normalizations per action. */
+typedef struct {
+  excenv_param_t static_params[EXCENV_MAX_STATIC];
+  excenv_param_t state_min[EXCENV_MAX_STATE];
+  excenv_param_t state_max[EXCENV_MAX_STATE];
+  excenv_param_t action_min[EXCENV_MAX_ACTION];
+  excenv_param_t action_max[EXCENV_MAX_ACTION];
+} excenv_props_t;
+
+/* Reference-tracking columns of the observation (generate_observation appends the normalised
+ * `state.reference.<name>` for every name in control_state, e.g. pendulum_env.py:322-328).
+ * n_control == 0 => no extra columns. reference[j] is a [B] array for state field control_idx[j]. */
+typedef struct {
+  int32_t n_control;
+  int32_t control_idx[EXCENV_MAX_CONTROL];
+  const void* reference[EXCENV_MAX_CONTROL];
+} excenv_control_t;
+
+/* ---- introspection -------------------------------------------------------------------- */
+int excenv_abi_version(void);
+const char* excenv_last_error(void);
+/* S = physical_state_dim, A = action_dim, O = observation width without control columns, P = #static params. */
+int excenv_env_dims(int env, int32_t* S, int32_t* A, int32_t* O, int32_t* P);
+/* Algorithmic HBM bytes per env-step: w*(S+A+S+O) for the step path,
+ * w*(A+O[+S]) for sim_ahead. */
+int64_t excenv_step_bytes(int env, int dtype);
+int64_t excenv_sim_ahead_bytes(int env, int dtype, int with_state_traj);
+
+/* ---- replaces CoreEnvironment.vmap_step (core_env.py:533-569) -------------------------
+ * and, for PMSM, PMSM.step (pmsm_env.py:851-883).
+ *   state_in  : S pointers to [B] arrays (physical_state fields, reference order)
+ *   action    : [B][A] row-major normalised action
+ *   state_out : S pointers to [B] arrays (may alias state_in element-for-element)
+ *   obs       : [B][O + n_control] row-major
+ */
+int excenv_step(int env, int solver, int dtype, int64_t B,
+                const excenv_props_t* props, const excenv_control_t* control, double tau,
+                const void* const* state_in, const void* action,
+                void* const* state_out, void* obs, void* stream);
+
+/* ---- replaces CoreEnvironment.vmap_sim_ahead (core_env.py:571-616) --------------------
+ * and PMSM.sim_ahead (pmsm_env.py:746-801). One persistent launch runs all N = K*substeps
+ * solver steps of step size obs_stepsize; action k is held for `substeps` solver steps.
+ *   actions    : K rows of A normalised actions per env, in `action_layout`
+ *   obs_traj   : N+1 rows of (O + n_control) per env, in `traj_layout` (row 0 = init state)
+ *   state_traj : NULL, or S pointers to [B][N+1] (env-major) / [N+1][B] (lane-major) arrays
+ *   last_state : S pointers to [B] arrays (row N of the trajectory; may alias state_in)
+ *   env_tau    : the environment's own tau; only PMSM reads it (its voltage-angle prediction uses
+ *                self.tau, pmsm_env.py:599-604,719-722, while the solver steps by obs_stepsize).
+ *                PMSM requires substeps == 1 (reference quirk, pmsm_env.py:787).
+ */
+int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32_t substeps,
+                     const excenv_props_t* props, const excenv_control_t* control, double obs_stepsize,
+                     double env_tau, const void* const* state_in, const void* actions, int action_layout,
+                     void* obs_traj, void* const* state_traj, int traj_layout,
+                     void* const* last_state, int semantics, void* stream);
+
+/* ---- device-math probes (tests only): out[i] = f(in[i]) for the in-kernel fp32 routines -- */
+int excenv_probe_math(int which /*0 sin,1 cos,2 wrap_angle*/, int dtype, int64_t n,
+                      const void* in, void* out, void* stream);
+
+#define EXCENV_OK 0
+#define EXCENV_EINVAL (-1)  /* bad enum / size / combination */
+#define EXCENV_ENULL (-2)   /* required pointer is NULL */
+#define EXCENV_EHIP (-3)    /* HIP runtime error at launch */
+#define EXCENV_EUNSUPPORTED (-4)
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXCENV_H */

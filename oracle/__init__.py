@@ -1,0 +1,237 @@
+"""ORACLE — test infrastructure only (see excenv_oracle.c header).
+
+ctypes/numpy front end of liboracle.so, the plain-C CPU restatement of the reference's
+vmap_step / vmap_sim_ahead arithmetic. Importable only from tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg; the product package never imports it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+MAX_STATE, MAX_ACTION, MAX_STATIC, MAX_CONTROL = 8, 2, 9, 8
+
+ENV_IDS = {
+    "pendulum": 0,
+    "mass_spring_damper": 1,
+    "cartpole": 2,
+    "acrobot": 3,
+    "fluid_tank": 4,
+    "pmsm": 5,
+}
+SOLVER_IDS = {"euler": 0, "rk4": 1, "tsit5": 2}
+DTYPE_IDS = {np.dtype(np.float32): 0, np.dtype(np.float64): 1}
+LAYOUT_ENV_MAJOR, LAYOUT_LANE_MAJOR = 0, 1
+SEM_STEP, SEM_AHEAD = 0, 1
+
+# (S, A, O, P) and field orders, mirroring include/excenv.h
+ENV_DIMS = {0: (2, 1, 2, 3), 1: (2, 1, 2, 3), 2: (4, 1, 4, 6), 3: (4, 1, 4, 9), 4: (1, 1, 1, 4), 5: (7, 2, 8, 7)}
+STATE_FIELDS = {
+    "pendulum": ["theta", "omega"],
+    "mass_spring_damper": ["deflection", "velocity"],
+    "cartpole": ["deflection", "velocity", "theta", "omega"],
+    "acrobot": ["theta_1", "theta_2", "omega_1", "omega_2"],
+    "fluid_tank": ["height"],
+    "pmsm": ["u_d_buffer", "u_q_buffer", "epsilon", "i_d", "i_q", "torque", "omega_el"],
+}
+ACTION_FIELDS = {
+    "pendulum": ["torque"],
+    "mass_spring_damper": ["force"],
+    "cartpole": ["force"],
+    "acrobot": ["torque"],
+    "fluid_tank": ["inflow"],
+    "pmsm": ["u_d", "u_q"],
+}
+PARAM_FIELDS = {
+    "pendulum": ["g", "l", "m"],
+    "mass_spring_damper": ["d", "k", "m"],
+    "cartpole": ["mu_p", "mu_c", "l", "m_p", "m_c", "g"],
+    "acrobot": ["g", "l_1", "l_2", "m_1", "m_2", "l_c1", "l_c2", "I_1", "I_2"],
+    "fluid_tank": ["base_area", "orifice_area", "c_d", "g"],
+    "pmsm": ["p", "r_s", "l_d", "l_q", "psi_p", "u_dc", "deadtime"],
+}
+
+
+class Param(ctypes.Structure):
+    _fields_ = [("value", ctypes.c_double), ("per_env", ctypes.c_void_p)]
+
+
+class Props(ctypes.Structure):
+    _fields_ = [
+        ("static_params", Param * MAX_STATIC),
+        ("state_min", Param * MAX_STATE),
+        ("state_max", Param * MAX_STATE),
+        ("action_min", Param * MAX_ACTION),
+        ("action_max", Param * MAX_ACTION),
+    ]
+
+
+class Control(ctypes.Structure):
+    _fields_ = [
+        ("n_control", ctypes.c_int32),
+        ("control_idx", ctypes.c_int32 * MAX_CONTROL),
+        ("reference", ctypes.c_void_p * MAX_CONTROL),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with the committed Makefile (gcc)."""
+    stale = not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in ("excenv_oracle.c", "oracle_body.inc", "Makefile")
+    )
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_step.restype = ctypes.c_int
+        _lib.oracle_sim_ahead.restype = ctypes.c_int
+        _lib.oracle_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def num_threads() -> int:
+    return int(lib().oracle_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    lib().oracle_set_num_threads(ctypes.c_int(n))
+
+
+def _fill(param: Param, v, dtype, B, keep):
+    if isinstance(v, np.ndarray) and v.ndim >= 1:
+        assert v.shape[0] == B, "per-env property must have length batch_size"
+        arr = np.ascontiguousarray(v, dtype=dtype)
+        keep.append(arr)
+        param.value = float("nan")
+        param.per_env = arr.ctypes.data
+    else:
+        param.value = float(v)
+        param.per_env = None
+
+
+def make_props(env: str, params: dict, phys_norm: dict, act_norm: dict, dtype, B: int):
+    """params: name->scalar|[B]; phys_norm/act_norm: name->(min,max) each scalar|[B]. Returns (Props, keepalive)."""
+    dtype = np.dtype(dtype)
+    keep: list = []
+    p = Props()
+    for j, name in enumerate(PARAM_FIELDS[env]):
+        _fill(p.static_params[j], params[name], dtype, B, keep)
+    for j, name in enumerate(STATE_FIELDS[env]):
+        lo, hi = phys_norm[name]
+        _fill(p.state_min[j], lo, dtype, B, keep)
+        _fill(p.state_max[j], hi, dtype, B, keep)
+    for j, name in enumerate(ACTION_FIELDS[env]):
+        lo, hi = act_norm[name]
+        _fill(p.action_min[j], lo, dtype, B, keep)
+        _fill(p.action_max[j], hi, dtype, B, keep)
+    return p, keep
+
+
+def _ptr_array(arrs: Sequence[np.ndarray]):
+    return (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def _make_control(env: str, control, dtype, B, keep):
+    if not control:
+        return None
+    c = Control()
+    c.n_control = len(control)
+    for j, (name, ref) in enumerate(control):
+        c.control_idx[j] = STATE_FIELDS[env].index(name)
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(ref, dtype=dtype), (B,)))
+        keep.append(arr)
+        c.reference[j] = arr.ctypes.data
+    return c
+
+
+def step(env: str, solver: str, state: Sequence[np.ndarray], action: np.ndarray, props: Props, tau: float,
+         control=None):
+    """One vmap_step. state: S arrays [B]; action [B,A]. control: list of (field_name, ref[B]).
+    Returns (obs [B,O+nc], new_state list)."""
+    dtype = np.dtype(state[0].dtype)
+    B = state[0].shape[0]
+    eid = ENV_IDS[env]
+    S, A, O, _ = ENV_DIMS[eid]
+    keep: list = []
+    ctl = _make_control(env, control, dtype, B, keep)
+    nc = len(control) if control else 0
+    st_in = [np.ascontiguousarray(s, dtype=dtype) for s in state]
+    act = np.ascontiguousarray(action, dtype=dtype).reshape(B, A)
+    st_out = [np.empty(B, dtype=dtype) for _ in range(S)]
+    obs = np.empty((B, O + nc), dtype=dtype)
+    rc = lib().oracle_step(
+        ctypes.c_int(eid), ctypes.c_int(SOLVER_IDS[solver]), ctypes.c_int(DTYPE_IDS[dtype]), ctypes.c_int64(B),
+        ctypes.byref(props), ctypes.byref(ctl) if ctl else None, ctypes.c_double(tau),
+        _ptr_array(st_in), ctypes.c_void_p(act.ctypes.data), _ptr_array(st_out), ctypes.c_void_p(obs.ctypes.data),
+    )
+    if rc != 0:
+        raise RuntimeError(f"oracle_step failed rc={rc}")
+    return obs, st_out
+
+
+def sim_ahead(env: str, solver: str, state: Sequence[np.ndarray], actions: np.ndarray, props: Props,
+              obs_stepsize: float, env_tau: Optional[float] = None, substeps: int = 1, semantics: int = SEM_STEP,
+              control=None, want_states: bool = True):
+    """vmap_sim_ahead on host arrays in the reference (env-major) layout.
+    actions [B,K,A] -> obs [B,N+1,O+nc], states list of [B,N+1], last_state list of [B]."""
+    dtype = np.dtype(state[0].dtype)
+    B = state[0].shape[0]
+    eid = ENV_IDS[env]
+    S, A, O, _ = ENV_DIMS[eid]
+    actions = np.ascontiguousarray(actions, dtype=dtype)
+    assert actions.ndim == 3 and actions.shape[0] == B and actions.shape[2] == A
+    K = actions.shape[1]
+    N = K * substeps
+    keep: list = []
+    ctl = _make_control(env, control, dtype, B, keep)
+    nc = len(control) if control else 0
+    st_in = [np.ascontiguousarray(s, dtype=dtype) for s in state]
+    obs = np.empty((B, N + 1, O + nc), dtype=dtype)
+    straj = [np.empty((B, N + 1), dtype=dtype) for _ in range(S)] if want_states else None
+    last = [np.empty(B, dtype=dtype) for _ in range(S)]
+    rc = lib().oracle_sim_ahead(
+        ctypes.c_int(eid), ctypes.c_int(SOLVER_IDS[solver]), ctypes.c_int(DTYPE_IDS[dtype]), ctypes.c_int64(B),
+        ctypes.c_int64(K), ctypes.c_int32(substeps), ctypes.byref(props), ctypes.byref(ctl) if ctl else None,
+        ctypes.c_double(obs_stepsize), ctypes.c_double(obs_stepsize if env_tau is None else env_tau),
+        _ptr_array(st_in), ctypes.c_void_p(actions.ctypes.data), ctypes.c_int(LAYOUT_ENV_MAJOR),
+        ctypes.c_void_p(obs.ctypes.data), _ptr_array(straj) if straj else None, ctypes.c_int(LAYOUT_ENV_MAJOR),
+        _ptr_array(last), ctypes.c_int(semantics),
+    )
+    if rc != 0:
+        raise RuntimeError(f"oracle_sim_ahead failed rc={rc}")
+    return obs, straj, last
+
+
+def denormalize(x, lo, hi):
+    """utils.py:16-17 on host arrays (used to bootstrap a state from a stored observation)."""
+    return (x + 1) / 2 * (hi - lo) + lo
+
+
+def state_from_observation(env: str, obs0: np.ndarray, phys_norm: dict):
+    """generate_state_from_observation (e.g. pendulum_env.py:331-364; pmsm_env.py:921-970) for one stored row."""
+    f = STATE_FIELDS[env]
+    if env == "pmsm":
+        normed = {
+            "u_d_buffer": obs0[6], "u_q_buffer": obs0[7], "epsilon": np.arctan2(obs0[5], obs0[4]) / np.pi,
+            "i_d": obs0[0], "i_q": obs0[1], "torque": obs0[3], "omega_el": obs0[2],
+        }
+    else:
+        normed = {name: obs0[j] for j, name in enumerate(f)}
+    return [np.asarray(denormalize(normed[name], *phys_norm[name])) for name in f]

@@ -1,0 +1,100 @@
+"""RK4 / Tsit5 in the oracle are "parity unpinned" (the reference has no test or fixture for any solver
+other than Euler). They are pinned here by (i) the Butcher order conditions of the tableau
+and (ii) the observed convergence order against the closed-form mass-spring-damper solution."""
+import itertools
+
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+import oracle
+
+TSIT5_C = np.array([0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0])
+TSIT5_A = np.zeros((6, 6))
+TSIT5_A[1, :1] = [0.161]
+TSIT5_A[2, :2] = [-0.008480655492356989, 0.335480655492357]
+TSIT5_A[3, :3] = [2.8971530571054935, -6.359448489975075, 4.3622954328695815]
+TSIT5_A[4, :4] = [5.325864828439257, -11.74888356406283, 7.4955393428898365, -0.09249506636175525]
+TSIT5_A[5, :5] = [5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383]
+TSIT5_B = np.array([0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
+                    2.324710524099774])
+
+
+def _order_conditions(A, b, c, order):
+    """Rooted-tree order conditions up to `order` (1,1,2,4,9 trees for orders 1..5)."""
+    e = np.ones_like(c)
+    Ac, Ac2, Ac3, AAc = A @ c, A @ c**2, A @ c**3, A @ (A @ c)
+    conds = [(b @ e, 1.0)]
+    if order >= 2:
+        conds += [(b @ c, 1 / 2)]
+    if order >= 3:
+        conds += [(b @ c**2, 1 / 3), (b @ Ac, 1 / 6)]
+    if order >= 4:
+        conds += [(b @ c**3, 1 / 4), (b @ (c * Ac), 1 / 8), (b @ Ac2, 1 / 12), (b @ AAc, 1 / 24)]
+    if order >= 5:
+        conds += [(b @ c**4, 1 / 5), (b @ (c**2 * Ac), 1 / 10), (b @ (c * Ac2), 1 / 15), (b @ (Ac * Ac), 1 / 20),
+                  (b @ (c * AAc), 1 / 30), (b @ Ac3, 1 / 20), (b @ (A @ (c * Ac)), 1 / 40),
+                  (b @ (A @ Ac2), 1 / 60), (b @ (A @ AAc), 1 / 120)]
+    return conds
+
+
+def test_tsit5_tableau_order_conditions():
+    assert np.allclose(TSIT5_A.sum(1), TSIT5_C, atol=1e-15)
+    conds = _order_conditions(TSIT5_A, TSIT5_B, TSIT5_C, 5)
+    assert len(conds) == 17
+    for got, want in conds:
+        assert abs(got - want) < 5e-15
+
+
+def test_rk4_tableau_order_conditions():
+    A = np.zeros((4, 4)); A[1, 0] = 0.5; A[2, 1] = 0.5; A[3, 2] = 1.0
+    b = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6]); c = np.array([0, 0.5, 0.5, 1.0])
+    for got, want in _order_conditions(A, b, c, 4):
+        assert abs(got - want) < 1e-15
+
+
+def _msd_exact(x0, v0, u, d, k, m, T):
+    M = np.array([[0, 1, 0], [-k / m, -d / m, 1 / m], [0, 0, 0]])
+    return (expm(M * T) @ np.array([x0, v0, u]))[:2]
+
+
+@pytest.mark.parametrize("solver,order", [("euler", 1), ("rk4", 4), ("tsit5", 5)])
+def test_convergence_order_on_mass_spring_damper(solver, order):
+    params = {"d": 1.0, "k": 100.0, "m": 1.0}
+    pn = {"deflection": (-10, 10), "velocity": (-10, 10)}
+    an = {"force": (-20, 20)}
+    props, keep = oracle.make_props("mass_spring_damper", params, pn, an, np.float64, 1)
+    T, a = 0.5, 0.35
+    exact = _msd_exact(1.0, -2.0, oracle.denormalize(a, -20, 20), 1.0, 100.0, 1.0, T)
+    errs = []
+    ns = [50, 100, 200] if order > 1 else [2000, 4000, 8000]
+    for n in ns:
+        st = [np.array([1.0]), np.array([-2.0])]
+        _, _, last = oracle.sim_ahead("mass_spring_damper", solver, st, np.full((1, n, 1), a), props, T / n)
+        errs.append(np.hypot(last[0][0] - exact[0], last[1][0] - exact[1]))
+    rates = [np.log2(errs[i] / errs[i + 1]) for i in range(2)]
+    for r in rates:
+        assert order - 0.25 < r < order + 0.4, (solver, errs, rates)
+
+
+def test_c1_stage_sees_next_action_only_in_ahead_semantics():
+    """core_env.py:435-439 warning: with higher-order solvers sim_ahead's c=1 stages read the next action.
+    With piecewise-constant actions that differ, SEM_AHEAD != SEM_STEP for rk4/tsit5 but == for euler;
+    with a constant action sequence both agree bit for bit."""
+    params = {"d": 1.0, "k": 100.0, "m": 1.0}
+    props, keep = oracle.make_props("mass_spring_damper", params, {"deflection": (-10, 10), "velocity": (-10, 10)},
+                                    {"force": (-20, 20)}, np.float64, 2)
+    st = [np.array([0.3, -0.2]), np.array([0.0, 1.0])]
+    rng = np.random.default_rng(1)
+    varying = rng.uniform(-1, 1, (2, 40, 1))
+    const = np.full((2, 40, 1), 0.25)
+    for solver in ("euler", "rk4", "tsit5"):
+        o_s, _, _ = oracle.sim_ahead("mass_spring_damper", solver, st, varying, props, 1e-2, semantics=oracle.SEM_STEP)
+        o_a, _, _ = oracle.sim_ahead("mass_spring_damper", solver, st, varying, props, 1e-2, semantics=oracle.SEM_AHEAD)
+        if solver == "euler":
+            assert np.array_equal(o_s, o_a)
+        else:
+            assert not np.array_equal(o_s, o_a) and np.allclose(o_s, o_a, atol=5e-3)
+        c_s, _, _ = oracle.sim_ahead("mass_spring_damper", solver, st, const, props, 1e-2, semantics=oracle.SEM_STEP)
+        c_a, _, _ = oracle.sim_ahead("mass_spring_damper", solver, st, const, props, 1e-2, semantics=oracle.SEM_AHEAD)
+        assert np.array_equal(c_s, c_a)
