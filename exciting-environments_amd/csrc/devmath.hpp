@@ -1,0 +1,112 @@
+// Device math for the batched ODE kernels (gfx950). Built with -ffp-contract=off: every + - * / and
+// sqrt below is a single IEEE-rounded operation in the order written, FMAs appear only where written
+// explicitly, so the trig-free environments are bit-identical to the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace excenv {
+
+template <typename T> struct K;  // constants, rounded from the Python doubles the reference uses
+template <> struct K<float> {
+  static constexpr float pi = 3.14159265358979323846f;
+  static constexpr float two_pi = 6.28318530717958647692f;
+  static constexpr float half_pi = 1.57079632679489661923f;
+  static constexpr float inv_two_pi = 0.15915494309189533577f;
+};
+template <> struct K<double> {
+  static constexpr double pi = 3.14159265358979323846;
+  static constexpr double two_pi = 6.28318530717958647692;
+  static constexpr double half_pi = 1.57079632679489661923;
+  static constexpr double inv_two_pi = 0.15915494309189533577;
+};
+
+__device__ __forceinline__ float xfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double xfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float xtrunc(float a) { return __builtin_truncf(a); }
+__device__ __forceinline__ double xtrunc(double a) { return __builtin_trunc(a); }
+__device__ __forceinline__ float xabs(float a) { return __builtin_fabsf(a); }
+__device__ __forceinline__ double xabs(double a) { return __builtin_fabs(a); }
+__device__ __forceinline__ float xsqrt(float a) { return __builtin_sqrtf(a); }  // correctly rounded (hipcc default)
+__device__ __forceinline__ double xsqrt(double a) { return __builtin_sqrt(a); }
+__device__ __forceinline__ float xfmod_slow(float a, float b) { return fmodf(a, b); }
+__device__ __forceinline__ double xfmod_slow(double a, double b) { return fmod(a, b); }
+
+// jnp.maximum / jnp.minimum against a bound: NaN in x propagates (jnp.clip semantics).
+template <typename T> __device__ __forceinline__ T max_nan(T x, T lo) { return (x < lo) ? lo : x; }
+template <typename T> __device__ __forceinline__ T min_nan(T x, T hi) { return (x > hi) ? hi : x; }
+// jnp.sign
+template <typename T> __device__ __forceinline__ T sign_of(T x) { return (x > T(0)) ? T(1) : ((x < T(0)) ? T(-1) : x); }
+
+// utils.py:13-17 — exactly this operation order
+template <typename T> __device__ __forceinline__ T normalize(T x, T lo, T hi) { return T(2) * (x - lo) / (hi - lo) - T(1); }
+template <typename T> __device__ __forceinline__ T denormalize(T x, T lo, T hi) { return (x + T(1)) / T(2) * (hi - lo) + lo; }
+
+// Exact C fmod(|x|, Y) for the compile-time divisor Y = 2*pi, without the library's bit-serial loop:
+// the truncated quotient is estimated with a reciprocal multiply (off by at most one for |q| < 2^22),
+// the remainder |x| - q*Y is then a single exactly-representable fma, re-derived if the estimate was off.
+// Falls back to the library for huge quotients. Then the jnp.remainder sign fix (result takes the
+// divisor's sign): lax.rem + select(add) — reference semantics of `%` in e.g. pendulum_env.py:188.
+template <typename T> __device__ __forceinline__ T pymod_two_pi(T x) {
+  const T y = K<T>::two_pi;
+  T ax = xabs(x);
+  T q = xtrunc(ax * K<T>::inv_two_pi);
+  T r;
+  if (__builtin_expect(!(q < T(4194304.0)), 0)) {
+    r = xfmod_slow(ax, y);  // also takes NaN / inf
+  } else {
+    r = xfma(-q, y, ax);
+    if (r < T(0)) {
+      q -= T(1);
+      r = xfma(-q, y, ax);
+    } else if (r >= y) {
+      q += T(1);
+      r = xfma(-q, y, ax);
+    }
+  }
+  r = (x < T(0)) ? -r : r;  // fmod carries the dividend's sign
+  if (r < T(0)) r = r + y;  // Python-style: shift negatives by the (positive) divisor
+  return r;
+}
+
+// ((theta + pi) % (2*pi)) - pi
+template <typename T> __device__ __forceinline__ T wrap_angle(T th) { return pymod_two_pi(th + K<T>::pi) - K<T>::pi; }
+
+// ---- sin / cos ---------------------------------------------------------------------------
+// fp64: device library. fp32: the arguments on this path are angles that were just wrapped into
+// [-pi, pi] (or advanced by a fraction of a step), so a 3-constant Cody-Waite reduction by pi/2 and the
+// Cephes single-precision minimax kernels give <= 1.5 ulp at ~25 VALU ops for the pair; |x| > 1024
+// falls back to the device library's full-range routine.
+__device__ __forceinline__ void sincos_t(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+
+__device__ __forceinline__ void sincos_t(float x, float& s, float& c) {
+  if (__builtin_expect(!(xabs(x) <= 1024.0f), 0)) {
+    s = ::sinf(x);
+    c = ::cosf(x);
+    return;
+  }
+  float n = __builtin_rintf(x * 0.63661977236758134308f);  // x * 2/pi
+  float r = xfma(-n, 1.5703125f, x);                        // pi/2 split in three (Cephes DP1..3 doubled)
+  r = xfma(-n, 4.837512969970703125e-4f, r);
+  r = xfma(-n, 7.54978995489188216e-8f, r);
+  int q = (int)n;
+  float z = r * r;
+  // sin(r) on |r| <= pi/4
+  float ps = xfma(-1.9515295891e-4f, z, 8.3321608736e-3f);
+  ps = xfma(ps, z, -1.6666654611e-1f);
+  float sr = xfma(ps * z, r, r);
+  // cos(r) on |r| <= pi/4
+  float pc = xfma(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+  pc = xfma(pc, z, 4.166664568298827e-2f);
+  float cr = xfma(pc * z, z, xfma(-0.5f, z, 1.0f));
+  float s0 = (q & 1) ? cr : sr;
+  float c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+__device__ __forceinline__ float sin_t(float x) { float s, c; sincos_t(x, s, c); return s; }
+__device__ __forceinline__ float cos_t(float x) { float s, c; sincos_t(x, s, c); return c; }
+__device__ __forceinline__ double sin_t(double x) { return ::sin(x); }
+__device__ __forceinline__ double cos_t(double x) { return ::cos(x); }
+
+}  // namespace excenv

@@ -1,0 +1,5 @@
+// Kernel instantiations for one environment (its own translation unit so the six compile in parallel).
+#include "launch.hpp"
+namespace excenv {
+EnvVTable vtable_pmsm() { return EnvEntry<Pmsm>::vtable(); }
+}  // namespace excenv

@@ -1,0 +1,332 @@
+// The two hot kernels: one fused step launch (vmap_step) and one persistent K-step launch (vmap_sim_ahead).
+// One lane per environment (V = 1) or V adjacent environments per lane with 16-byte vector accesses
+// (lane-major trajectories only). State, parameters and RK stages stay in registers for the whole trajectory.
+#pragma once
+#include "rk.hpp"
+
+namespace excenv {
+
+constexpr int BLOCK = 256;
+
+// Property leaves in kernel-argument order: P statics, S mins, S maxs, A mins, A maxs.
+template <typename T, class M> struct KProps {
+  static constexpr int N = M::P + 2 * M::S + 2 * M::A;
+  T scalar[N];
+  const T* ptr[N];  // per-env [B] array or nullptr
+};
+
+template <typename T, class M> struct StepArgs {
+  KProps<T, M> kp;
+  int64_t B;
+  const T* state_in[M::S];
+  T* state_out[M::S];
+  const T* action;  // [B][A]
+  T* obs;           // [B][O + n_control]
+  int32_t n_control;
+  int32_t control_idx[EXCENV_MAX_CONTROL];
+  const T* reference[EXCENV_MAX_CONTROL];
+  T dt, env_tau, adv_coef;
+};
+
+template <typename T, class M> struct SimArgs {
+  KProps<T, M> kp;
+  int64_t B, K;
+  int32_t substeps;
+  int32_t n_control;
+  const T* state_in[M::S];
+  T* last_state[M::S];
+  const T* actions;
+  int64_t a_sb, a_sk, a_sc;  // element strides of (env, action step, component)
+  T* obs;
+  int64_t o_sb, o_sk, o_sc;
+  T* straj[M::S];  // straj[0] == nullptr: no state trajectory
+  int64_t s_sb, s_sk;
+  int32_t control_idx[EXCENV_MAX_CONTROL];
+  const T* reference[EXCENV_MAX_CONTROL];
+  T dt, env_tau, adv_coef;
+};
+
+template <bool BATCHED, typename T, class M>
+__device__ __forceinline__ void load_ctx(Ctx<T, M>& c, const KProps<T, M>& kp, int64_t i, T dt, T env_tau, T adv_coef) {
+  auto get = [&](int j) -> T {
+    if constexpr (BATCHED) {
+      const T* p = kp.ptr[j];
+      return p ? p[i] : kp.scalar[j];
+    } else {
+      return kp.scalar[j];
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < M::P; ++j) c.P[j] = get(j);
+#pragma unroll
+  for (int j = 0; j < M::S; ++j) {
+    c.smin[j] = get(M::P + j);
+    c.smax[j] = get(M::P + M::S + j);
+  }
+#pragma unroll
+  for (int j = 0; j < M::A; ++j) {
+    c.amin[j] = get(M::P + 2 * M::S + j);
+    c.amax[j] = get(M::P + 2 * M::S + M::A + j);
+  }
+  c.dt = dt;
+  c.env_tau = env_tau;
+  c.adv_coef = adv_coef;
+}
+
+// ---- vector access helpers ---------------------------------------------------------------
+template <typename T, int V> struct VecOf;
+template <> struct VecOf<float, 1> { using type = float; };
+template <> struct VecOf<float, 2> { using type = float2; };
+template <> struct VecOf<float, 4> { using type = float4; };
+template <> struct VecOf<double, 1> { using type = double; };
+template <> struct VecOf<double, 2> { using type = double2; };
+
+template <typename T, int V> __device__ __forceinline__ void load_v(const T* p, T (&out)[V]) {
+  if constexpr (V == 1) {
+    out[0] = *p;
+  } else {
+    using VT = typename VecOf<T, V>::type;
+    const VT v = *reinterpret_cast<const VT*>(p);
+    const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+    for (int j = 0; j < V; ++j) out[j] = e[j];
+  }
+}
+template <typename T, int V> __device__ __forceinline__ void store_v(T* p, const T (&in)[V]) {
+  if constexpr (V == 1) {
+    *p = in[0];
+  } else {
+    using VT = typename VecOf<T, V>::type;
+    VT v;
+    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int j = 0; j < V; ++j) e[j] = in[j];
+    *reinterpret_cast<VT*>(p) = v;
+  }
+}
+
+// Row-major row of N values per lane (obs[B][O], action[B][A]): widest power-of-two chunks up to 16 bytes.
+template <typename T, int N> __device__ __forceinline__ void store_row(T* dst, const T (&v)[N]) {
+  constexpr int MAXV = 16 / sizeof(T);
+  constexpr int W = (N % MAXV == 0) ? MAXV : ((N % 2 == 0 && MAXV >= 2) ? 2 : 1);
+#pragma unroll
+  for (int j = 0; j < N; j += W) {
+    T tmp[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) tmp[w] = v[j + w];
+    store_v<T, W>(dst + j, tmp);
+  }
+}
+template <typename T, int N> __device__ __forceinline__ void load_row(const T* src, T (&v)[N]) {
+  constexpr int MAXV = 16 / sizeof(T);
+  constexpr int W = (N % MAXV == 0) ? MAXV : ((N % 2 == 0 && MAXV >= 2) ? 2 : 1);
+#pragma unroll
+  for (int j = 0; j < N; j += W) {
+    T tmp[W];
+    load_v<T, W>(src + j, tmp);
+#pragma unroll
+    for (int w = 0; w < W; ++w) v[j + w] = tmp[w];
+  }
+}
+
+// ---- vmap_step: one fused launch (reference core_env.py:533-569) ---------------------------
+template <class M, typename T, int SOLVER, bool BATCHED>
+__global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
+  constexpr int S = M::S, A = M::A, O = M::O;
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= ka.B) return;
+  Ctx<T, M> c;
+  load_ctx<BATCHED>(c, ka.kp, i, ka.dt, ka.env_tau, ka.adv_coef);
+  T st[S], a[A], ob[O];
+#pragma unroll
+  for (int j = 0; j < S; ++j) st[j] = ka.state_in[j][i];
+  load_row<T, A>(ka.action + i * A, a);
+  env_step<M, SOLVER>(st, a, c);
+  M::observe(st, c, ob);
+#pragma unroll
+  for (int j = 0; j < S; ++j) ka.state_out[j][i] = st[j];
+  if (ka.n_control == 0) {
+    store_row<T, O>(ka.obs + i * O, ob);
+  } else {
+    T* row = ka.obs + i * (O + ka.n_control);
+#pragma unroll
+    for (int j = 0; j < O; ++j) row[j] = ob[j];
+    for (int j = 0; j < ka.n_control; ++j) {
+      const int f = ka.control_idx[j];
+      const T r = ka.reference[j][i];
+      T lo = c.smin[0], hi = c.smax[0];
+#pragma unroll
+      for (int q = 1; q < S; ++q) {
+        lo = (f == q) ? c.smin[q] : lo;
+        hi = (f == q) ? c.smax[q] : hi;
+      }
+      row[O + j] = normalize(r, lo, hi);
+    }
+  }
+}
+
+// ---- vmap_sim_ahead: one persistent launch for all N = K*substeps solver steps ------------------
+// (reference core_env.py:571-616 + each env's _ode_solver_simulate_ahead; PMSM.sim_ahead pmsm_env.py:746-801)
+template <class M, typename T, int SOLVER, bool AHEAD, bool BATCHED, int V>
+__global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka) {
+  constexpr int S = M::S, A = M::A, O = M::O;
+  static_assert(!(BATCHED && V > 1), "vectorised lanes share one uniform property set");
+  // Addressing: every access is (wave-uniform base, kept in SGPRs) + (small unsigned per-lane offset),
+  // so one VGPR of offset serves all 2*S + A + O streams (global_* saddr form).
+  const int64_t blk0 = (int64_t)blockIdx.x * (BLOCK * V);  // first env of this workgroup
+  const unsigned lane_env = threadIdx.x * V;
+  const int64_t i0 = blk0 + lane_env;
+  if (i0 >= ka.B) return;  // host guarantees B % V == 0
+  Ctx<T, M> c;
+  load_ctx<BATCHED>(c, ka.kp, i0, ka.dt, ka.env_tau, ka.adv_coef);
+
+  T st[V][S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    T tmp[V];
+    load_v<T, V>(ka.state_in[j] + blk0 + lane_env, tmp);
+#pragma unroll
+    for (int v = 0; v < V; ++v) st[v][j] = tmp[v];
+  }
+  AheadAux<T> aux[V];
+  if constexpr (AHEAD && M::ID == EXCENV_PMSM) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      aux[v].eps0 = st[v][2];
+      aux[v].buf0[0] = aux[v].prev_clip[0] = st[v][0];
+      aux[v].buf0[1] = aux[v].prev_clip[1] = st[v][1];
+    }
+  }
+  const bool deadtime_on = (M::ID == EXCENV_PMSM) ? (c.P[M::P - 1] > T(0)) : false;
+
+  const int64_t N = ka.K * ka.substeps;
+  // V > 1 implies env stride 1; for V == 1 the host has checked that 256 * stride * sizeof(T) < 2^31
+  const T* a_blk = ka.actions + blk0 * ((V == 1) ? ka.a_sb : 1);
+  T* o_blk = ka.obs + blk0 * ((V == 1) ? ka.o_sb : 1);
+  const int64_t s_blk = blk0 * ((V == 1) ? ka.s_sb : 1);
+  const unsigned a_lane = (V == 1) ? threadIdx.x * (unsigned)ka.a_sb : lane_env;
+  const unsigned o_lane = (V == 1) ? threadIdx.x * (unsigned)ka.o_sb : lane_env;
+  const unsigned s_lane = (V == 1) ? threadIdx.x * (unsigned)ka.s_sb : lane_env;
+  const bool with_states = ka.straj[0] != nullptr;
+
+  T a_cur[V][A], a_nxt[V][A];
+  auto load_action = [&](int64_t k, T (&dst)[V][A]) {
+#pragma unroll
+    for (int q = 0; q < A; ++q) {
+      T tmp[V];
+      const T* row = a_blk + k * ka.a_sk + q * ka.a_sc;
+      load_v<T, V>(row + a_lane, tmp);
+#pragma unroll
+      for (int v = 0; v < V; ++v) dst[v][q] = tmp[v];
+    }
+  };
+  if (N > 0) load_action(0, a_cur);
+
+  int64_t k = 0;
+  int32_t sub = 0;
+  for (int64_t n = 0;; ++n) {
+    // action row of solver step n+1, requested a whole step ahead of its use
+    int64_t kn = k;
+    int32_t subn = sub + 1;
+    if (subn == ka.substeps) { subn = 0; kn = k + 1; }
+    const int64_t k1 = (kn < ka.K) ? kn : ka.K - 1;
+    if (n < N) load_action(k1, a_nxt);
+
+    // ---- save row n ----
+    T sv[V][S];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+#pragma unroll
+      for (int j = 0; j < S; ++j) sv[v][j] = st[v][j];
+      if constexpr (AHEAD) {
+        M::post(sv[v], c);
+        if constexpr (M::ID == EXCENV_PMSM) {  // pmsm_env.py:785-791
+          if (deadtime_on) {
+            sv[v][0] = (n == 0) ? aux[v].buf0[0] : aux[v].prev_clip[0];
+            sv[v][1] = (n == 0) ? aux[v].buf0[1] : aux[v].prev_clip[1];
+          } else {
+            sv[v][0] = T(0);
+            sv[v][1] = T(0);
+          }
+        }
+      }
+    }
+    {
+      T ob[V][O];
+#pragma unroll
+      for (int v = 0; v < V; ++v) M::observe(sv[v], c, ob[v]);
+      T* orow = o_blk + n * ka.o_sk;
+#pragma unroll
+      for (int q = 0; q < O; ++q) {
+        T tmp[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) tmp[v] = ob[v][q];
+        store_v<T, V>(orow + q * ka.o_sc + o_lane, tmp);
+      }
+      if (ka.n_control > 0) {  // reference-tracking columns (constant along the trajectory)
+        for (int j = 0; j < ka.n_control; ++j) {
+          const int f = ka.control_idx[j];
+          T lo = c.smin[0], hi = c.smax[0];
+#pragma unroll
+          for (int q = 1; q < S; ++q) {
+            lo = (f == q) ? c.smin[q] : lo;
+            hi = (f == q) ? c.smax[q] : hi;
+          }
+          T tmp[V];
+#pragma unroll
+          for (int v = 0; v < V; ++v) tmp[v] = normalize(ka.reference[j][i0 + v], lo, hi);
+          store_v<T, V>(orow + (O + j) * ka.o_sc + o_lane, tmp);
+        }
+      }
+      if (with_states) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          T tmp[V];
+#pragma unroll
+          for (int v = 0; v < V; ++v) tmp[v] = sv[v][j];
+          store_v<T, V>(ka.straj[j] + s_blk + n * ka.s_sk + s_lane, tmp);
+        }
+      }
+    }
+    if (n == N) {
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        T tmp[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) tmp[v] = sv[v][j];
+        store_v<T, V>(ka.last_state[j] + blk0 + lane_env, tmp);
+      }
+      break;
+    }
+
+    // ---- advance one solver step ----
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if constexpr (AHEAD) {
+        env_advance_raw<M, SOLVER>(st[v], a_cur[v], a_nxt[v], k, k1, c, aux[v]);
+      } else {
+        env_step<M, SOLVER>(st[v], a_cur[v], c);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int q = 0; q < A; ++q) a_cur[v][q] = a_nxt[v][q];
+    k = kn;
+    sub = subn;
+  }
+}
+
+// ---- probes for the in-kernel math (tests) ---------------------------------------------------
+template <typename T> __global__ void probe_kernel(int which, int64_t n, const T* in, T* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T x = in[i];
+  T r;
+  if (which == 0) r = sin_t(x);
+  else if (which == 1) r = cos_t(x);
+  else r = wrap_angle(x);
+  out[i] = r;
+}
+
+}  // namespace excenv

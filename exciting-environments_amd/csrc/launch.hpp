@@ -1,0 +1,246 @@
+// Host-side glue between the C ABI (include/excenv.h) and the templated kernels: converts the untyped
+// call into typed kernel arguments, picks the instantiation, enqueues it on the caller's stream.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "kernels.hpp"
+
+namespace excenv {
+
+void set_error(const char* fmt, ...);
+
+struct StepCall {
+  int solver, dtype;
+  int64_t B;
+  const excenv_props_t* props;
+  const excenv_control_t* control;  // nullptr when n_control == 0
+  double tau;
+  const void* const* state_in;
+  const void* action;
+  void* const* state_out;
+  void* obs;
+  hipStream_t stream;
+};
+
+struct SimCall {
+  int solver, dtype;
+  int64_t B, K;
+  int32_t substeps;
+  const excenv_props_t* props;
+  const excenv_control_t* control;
+  double obs_stepsize, env_tau;
+  const void* const* state_in;
+  const void* actions;
+  int action_layout;
+  void* obs_traj;
+  void* const* state_traj;  // may be nullptr
+  int traj_layout;
+  void* const* last_state;
+  int semantics;
+  int vec_pref;  // 0 auto, else forced envs-per-lane (1, 2, 4)
+  hipStream_t stream;
+};
+
+struct EnvVTable {
+  int S, A, O, P;
+  int (*step)(const StepCall&);
+  int (*sim)(const SimCall&);
+};
+
+template <typename T, class M>
+static bool fill_props(KProps<T, M>& kp, const excenv_props_t* p) {
+  bool batched = false;
+  int n = 0;
+  auto put = [&](const excenv_param_t& q) {
+    kp.scalar[n] = (T)q.value;
+    kp.ptr[n] = (const T*)q.per_env;
+    batched |= (q.per_env != nullptr);
+    ++n;
+  };
+  for (int j = 0; j < M::P; ++j) put(p->static_params[j]);
+  for (int j = 0; j < M::S; ++j) put(p->state_min[j]);
+  for (int j = 0; j < M::S; ++j) put(p->state_max[j]);
+  for (int j = 0; j < M::A; ++j) put(p->action_min[j]);
+  for (int j = 0; j < M::A; ++j) put(p->action_max[j]);
+  return batched;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return EXCENV_EHIP;
+  }
+  return EXCENV_OK;
+}
+
+// PMSM: deadtime must be a broadcast scalar in {0, 1} (only one buffered action is representable in the
+// reference's state, pmsm_env.py:866-875); returns the double-folded (deadtime + 0.5) * tau.
+template <class M> static int pmsm_coef(const excenv_props_t* p, double env_tau, double* coef) {
+  *coef = 0.0;
+  if constexpr (M::ID == EXCENV_PMSM) {
+    const excenv_param_t& d = p->static_params[6];
+    if (d.per_env) {
+      set_error("PMSM: static_params.deadtime must be a scalar, not a per-env array");
+      return EXCENV_EUNSUPPORTED;
+    }
+    if (!(d.value == 0.0 || d.value == 1.0)) {
+      set_error("PMSM: deadtime must be 0 or 1 (got %g)", d.value);
+      return EXCENV_EUNSUPPORTED;
+    }
+    *coef = (d.value + 0.5) * env_tau;
+  }
+  return EXCENV_OK;
+}
+
+template <class M, typename T> static int launch_step(const StepCall& sc) {
+  StepArgs<T, M> ka;
+  std::memset(&ka, 0, sizeof(ka));
+  const bool batched = fill_props<T, M>(ka.kp, sc.props);
+  double coef;
+  if (int rc = pmsm_coef<M>(sc.props, sc.tau, &coef)) return rc;
+  ka.B = sc.B;
+  for (int j = 0; j < M::S; ++j) {
+    if (!sc.state_in[j] || !sc.state_out[j]) { set_error("excenv_step: state pointer %d is NULL", j); return EXCENV_ENULL; }
+    ka.state_in[j] = (const T*)sc.state_in[j];
+    ka.state_out[j] = (T*)sc.state_out[j];
+  }
+  ka.action = (const T*)sc.action;
+  ka.obs = (T*)sc.obs;
+  ka.n_control = sc.control ? sc.control->n_control : 0;
+  for (int j = 0; j < ka.n_control; ++j) {
+    ka.control_idx[j] = sc.control->control_idx[j];
+    ka.reference[j] = (const T*)sc.control->reference[j];
+  }
+  ka.dt = (T)sc.tau;
+  ka.env_tau = (T)sc.tau;
+  ka.adv_coef = (T)coef;
+  if (!aligned16(ka.action) || !aligned16(ka.obs)) {
+    set_error("excenv_step: action and obs must be 16-byte aligned");
+    return EXCENV_EINVAL;
+  }
+  if (sc.B == 0) return EXCENV_OK;
+  const dim3 grid((unsigned)((sc.B + BLOCK - 1) / BLOCK)), block(BLOCK);
+#define EXCENV_STEP_CASE(SOLV)                                                                         \
+  case SOLV:                                                                                           \
+    if (batched) hipLaunchKernelGGL((step_kernel<M, T, SOLV, true>), grid, block, 0, sc.stream, ka);   \
+    else hipLaunchKernelGGL((step_kernel<M, T, SOLV, false>), grid, block, 0, sc.stream, ka);          \
+    break;
+  switch (sc.solver) {
+    EXCENV_STEP_CASE(EXCENV_EULER)
+    EXCENV_STEP_CASE(EXCENV_RK4)
+    EXCENV_STEP_CASE(EXCENV_TSIT5)
+    default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
+  }
+#undef EXCENV_STEP_CASE
+  return check_launch("excenv_step");
+}
+
+template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(const SimCall& sc, const SimArgs<T, M>& ka,
+                                                                                 bool batched, int V) {
+  const int64_t lanes = sc.B / V;
+  const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
+  if (batched) {
+    hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, true, 1>), grid, block, 0, sc.stream, ka);
+    return;
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (V == 4) { hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 4>), grid, block, 0, sc.stream, ka); return; }
+  }
+  if (V == 2) { hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 2>), grid, block, 0, sc.stream, ka); return; }
+  hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 1>), grid, block, 0, sc.stream, ka);
+}
+
+template <class M, typename T> static int launch_sim(const SimCall& sc) {
+  SimArgs<T, M> ka;
+  std::memset(&ka, 0, sizeof(ka));
+  const bool batched = fill_props<T, M>(ka.kp, sc.props);
+  double coef;
+  if (int rc = pmsm_coef<M>(sc.props, sc.env_tau, &coef)) return rc;
+  if (M::ID == EXCENV_PMSM && sc.substeps != 1) {
+    set_error("PMSM: obs_stepsize must equal action_stepsize (reference pmsm_env.py:787)");
+    return EXCENV_EUNSUPPORTED;
+  }
+  ka.B = sc.B;
+  ka.K = sc.K;
+  ka.substeps = sc.substeps;
+  ka.n_control = sc.control ? sc.control->n_control : 0;
+  const int64_t N = sc.K * sc.substeps;
+  const int64_t OW = M::O + ka.n_control;
+  bool vec_ok = !batched;
+  for (int j = 0; j < M::S; ++j) {
+    if (!sc.state_in[j] || !sc.last_state[j]) { set_error("excenv_sim_ahead: state pointer %d is NULL", j); return EXCENV_ENULL; }
+    ka.state_in[j] = (const T*)sc.state_in[j];
+    ka.last_state[j] = (T*)sc.last_state[j];
+    ka.straj[j] = sc.state_traj ? (T*)sc.state_traj[j] : nullptr;
+    if (sc.state_traj && !sc.state_traj[j]) { set_error("excenv_sim_ahead: state_traj pointer %d is NULL", j); return EXCENV_ENULL; }
+    vec_ok &= aligned16(ka.state_in[j]) && aligned16(ka.last_state[j]) && aligned16(ka.straj[j]);
+  }
+  ka.actions = (const T*)sc.actions;
+  ka.obs = (T*)sc.obs_traj;
+  if (sc.action_layout == EXCENV_LAYOUT_ENV_MAJOR) { ka.a_sb = sc.K * M::A; ka.a_sk = M::A; ka.a_sc = 1; }
+  else { ka.a_sb = 1; ka.a_sk = (int64_t)M::A * sc.B; ka.a_sc = sc.B; }
+  if (sc.traj_layout == EXCENV_LAYOUT_ENV_MAJOR) {
+    ka.o_sb = (N + 1) * OW; ka.o_sk = OW; ka.o_sc = 1;
+    ka.s_sb = N + 1; ka.s_sk = 1;
+  } else {
+    ka.o_sb = 1; ka.o_sk = OW * sc.B; ka.o_sc = sc.B;
+    ka.s_sb = 1; ka.s_sk = sc.B;
+  }
+  for (int j = 0; j < ka.n_control; ++j) {
+    ka.control_idx[j] = sc.control->control_idx[j];
+    ka.reference[j] = (const T*)sc.control->reference[j];
+    vec_ok &= aligned16(ka.reference[j]);
+  }
+  ka.dt = (T)sc.obs_stepsize;
+  ka.env_tau = (T)sc.env_tau;
+  ka.adv_coef = (T)coef;
+  if (sc.B == 0) return EXCENV_OK;
+  {  // per-lane offsets are 32-bit: 256 lanes * env stride * element size must stay below 2^31
+    const int64_t lim = ((int64_t)1 << 31) / (BLOCK * (int64_t)sizeof(T));
+    if (ka.a_sb >= lim || ka.o_sb >= lim || ka.s_sb >= lim) {
+      set_error("excenv_sim_ahead: env-major trajectory too long for one call ((N+1)*O must be < %lld); chunk K",
+                (long long)lim);
+      return EXCENV_EUNSUPPORTED;
+    }
+  }
+
+  vec_ok &= (sc.action_layout == EXCENV_LAYOUT_LANE_MAJOR) && (sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR);
+  vec_ok &= aligned16(ka.actions) && aligned16(ka.obs);
+  constexpr int VMAX = 16 / (int)sizeof(T);
+  int V = 1;
+  if (vec_ok) {
+    int want = sc.vec_pref > 0 ? sc.vec_pref : VMAX;
+    if (want > VMAX) want = VMAX;
+    while (want > 1 && (sc.B % want) != 0) want >>= 1;
+    V = want;
+  }
+#define EXCENV_SIM_CASE(SOLV)                                                         \
+  case SOLV:                                                                          \
+    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(sc, ka, batched, V);  \
+    else launch_sim_v<M, T, SOLV, false>(sc, ka, batched, V);                         \
+    break;
+  switch (sc.solver) {
+    EXCENV_SIM_CASE(EXCENV_EULER)
+    EXCENV_SIM_CASE(EXCENV_RK4)
+    EXCENV_SIM_CASE(EXCENV_TSIT5)
+    default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
+  }
+#undef EXCENV_SIM_CASE
+  return check_launch("excenv_sim_ahead");
+}
+
+template <template <typename> class MT> struct EnvEntry {
+  static int step(const StepCall& sc) {
+    return sc.dtype == EXCENV_F32 ? launch_step<MT<float>, float>(sc) : launch_step<MT<double>, double>(sc);
+  }
+  static int sim(const SimCall& sc) {
+    return sc.dtype == EXCENV_F32 ? launch_sim<MT<float>, float>(sc) : launch_sim<MT<double>, double>(sc);
+  }
+  static EnvVTable vtable() { return EnvVTable{MT<float>::S, MT<float>::A, MT<float>::O, MT<float>::P, &step, &sim}; }
+};
+
+}  // namespace excenv

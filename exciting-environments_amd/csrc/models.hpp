@@ -1,0 +1,240 @@
+// The six vector fields and their step pre/post-processing, one lane per environment instance.
+// Each expression keeps the reference's operation order (citations into /root/reference/exciting_environments).
+#pragma once
+#include "../../include/excenv.h"
+#include "devmath.hpp"
+
+namespace excenv {
+
+// Per-lane (or wave-uniform, when no property is batched) environment properties.
+template <typename T, class M> struct Ctx {
+  T P[M::P];
+  T smin[M::S], smax[M::S];
+  T amin[M::A], amax[M::A];
+  T dt;        // solver step (obs_stepsize; == tau on the step path)
+  T env_tau;   // self.tau (PMSM angle prediction)
+  T adv_coef;  // PMSM: (deadtime + 0.5) * tau, folded in double on the host (pmsm_env.py:599-604)
+};
+
+// ---- Pendulum: pendulum_env.py:144-150,188 ; P = (g,l,m) --------------------------------
+template <typename T> struct Pendulum {
+  static constexpr int ID = EXCENV_PENDULUM, S = 2, A = 1, O = 2, P = 3, NY = 2;
+  using C = Ctx<T, Pendulum>;
+  __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; y[1] = st[1]; }
+  __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; st[1] = y[1]; }
+  __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
+    const T g = c.P[0], l = c.P[1], m = c.P[2];
+    dy[1] = (u[0] + l * m * g * sin_t(y[0])) / (m * (l * l));
+    dy[0] = y[1];
+  }
+  __device__ static __forceinline__ void post(T (&st)[S], const C&) { st[0] = wrap_angle(st[0]); }
+  __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
+    ob[0] = normalize(st[0], c.smin[0], c.smax[0]);
+    ob[1] = normalize(st[1], c.smin[1], c.smax[1]);
+  }
+};
+
+// ---- MassSpringDamper: mass_spring_damper_env.py:142-148 ; P = (d,k,m) ---------------------
+template <typename T> struct MassSpringDamper {
+  static constexpr int ID = EXCENV_MASS_SPRING_DAMPER, S = 2, A = 1, O = 2, P = 3, NY = 2;
+  using C = Ctx<T, MassSpringDamper>;
+  __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; y[1] = st[1]; }
+  __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; st[1] = y[1]; }
+  __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
+    const T d = c.P[0], k = c.P[1], m = c.P[2];
+    dy[1] = (u[0] - d * y[1] - k * y[0]) / m;
+    dy[0] = y[1];
+  }
+  __device__ static __forceinline__ void post(T (&)[S], const C&) {}
+  __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
+    ob[0] = normalize(st[0], c.smin[0], c.smax[0]);
+    ob[1] = normalize(st[1], c.smin[1], c.smax[1]);
+  }
+};
+
+// ---- CartPole: cart_pole_env.py:159-180,229 ; P = (mu_p,mu_c,l,m_p,m_c,g) -----------------
+template <typename T> struct CartPole {
+  static constexpr int ID = EXCENV_CART_POLE, S = 4, A = 1, O = 4, P = 6, NY = 4;
+  using C = Ctx<T, CartPole>;
+  __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = st[j];
+  }
+  __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st[j] = y[j];
+  }
+  __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
+    const T mu_p = c.P[0], mu_c = c.P[1], l = c.P[2], m_p = c.P[3], m_c = c.P[4], g = c.P[5];
+    const T velocity = y[1], theta = y[2], omega = y[3];
+    T s, co;
+    sincos_t(theta, s, co);
+    const T d_omega =
+        (g * s + co * ((-u[0] - m_p * l * (omega * omega) * s + mu_c * sign_of(velocity)) / (m_c + m_p)) -
+         (mu_p * omega) / (m_p * l)) /
+        (l * (T(4.0 / 3.0) - (m_p * (co * co)) / (m_c + m_p)));
+    const T d_velocity =
+        (u[0] + m_p * l * ((omega * omega) * s - d_omega * co) - mu_c * sign_of(velocity)) / (m_c + m_p);
+    dy[0] = velocity;
+    dy[1] = d_velocity;
+    dy[2] = omega;
+    dy[3] = d_omega;
+  }
+  __device__ static __forceinline__ void post(T (&st)[S], const C&) { st[2] = wrap_angle(st[2]); }
+  __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ob[j] = normalize(st[j], c.smin[j], c.smax[j]);
+  }
+};
+
+// ---- Acrobot: acrobot_env.py:171-197,247-248 ; P = (g,l_1,l_2,m_1,m_2,l_c1,l_c2,I_1,I_2) ----
+template <typename T> struct Acrobot {
+  static constexpr int ID = EXCENV_ACROBOT, S = 4, A = 1, O = 4, P = 9, NY = 4;
+  using C = Ctx<T, Acrobot>;
+  __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = st[j];
+  }
+  __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st[j] = y[j];
+  }
+  __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
+    const T g = c.P[0], l_1 = c.P[1], m_1 = c.P[3], m_2 = c.P[4], l_c1 = c.P[5], l_c2 = c.P[6], I_1 = c.P[7], I_2 = c.P[8];
+    const T theta_1 = y[0], theta_2 = y[1], omega_1 = y[2], omega_2 = y[3];
+    T s2, c2;
+    sincos_t(theta_2, s2, c2);
+    const T d_11 = m_1 * (l_c1 * l_c1) + m_2 * (l_1 * l_1 + l_c2 * l_c2 + T(2) * l_1 * l_c2 * c2) + I_1 + I_2;
+    const T d_12 = m_2 * (l_c2 * l_c2 + l_1 * l_c2 * c2) + I_2;
+    const T d_22 = m_2 * (l_c2 * l_c2) + I_2;
+    const T h_1 = -m_2 * l_1 * l_c2 * s2 * (omega_2 * omega_2) - T(2) * m_2 * l_1 * l_c2 * s2 * omega_1 * omega_2;
+    const T h_2 = m_2 * l_1 * l_c2 * s2 * (omega_1 * omega_1);
+    const T cA = cos_t(theta_1 + K<T>::half_pi);
+    const T cB = cos_t(theta_1 + theta_2 + K<T>::half_pi);
+    const T phi_1 = (m_1 * l_c1 + m_2 * l_1) * g * cA + m_2 * l_c2 * g * cB;
+    const T phi_2 = m_2 * l_c2 * g * cB;
+    const T d_omega_1 = T(1) / (d_12 - d_22 / d_12 * d_11) * (u[0] + d_22 / d_12 * (h_1 + phi_1) - h_2 - phi_2);
+    const T d_omega_2 = (-d_11 * d_omega_1 - h_1 - phi_1) / d_12;
+    dy[0] = omega_1;
+    dy[1] = omega_2;
+    dy[2] = d_omega_1;
+    dy[3] = d_omega_2;
+  }
+  __device__ static __forceinline__ void post(T (&st)[S], const C&) {
+    st[0] = wrap_angle(st[0]);
+    st[1] = wrap_angle(st[1]);
+  }
+  __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ob[j] = normalize(st[j], c.smin[j], c.smax[j]);
+  }
+};
+
+// ---- FluidTank: fluid_tank_env.py:97-106,146 ; P = (base_area, orifice_area, c_d, g) ---------
+template <typename T> struct FluidTank {
+  static constexpr int ID = EXCENV_FLUID_TANK, S = 1, A = 1, O = 1, P = 4, NY = 1;
+  using C = Ctx<T, FluidTank>;
+  __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; }
+  __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; }
+  __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
+    const T base_area = c.P[0], orifice_area = c.P[1], c_d = c.P[2], g = c.P[3];
+    const T h = max_nan(y[0], T(0));
+    dy[0] = u[0] / base_area - c_d * orifice_area / base_area * xsqrt(T(2) * g * h);
+  }
+  __device__ static __forceinline__ void post(T (&st)[S], const C&) { st[0] = max_nan(st[0], T(0)); }
+  __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
+    ob[0] = normalize(st[0], c.smin[0], c.smax[0]);
+  }
+};
+
+// ---- PMSM (linear dq-frame model): pmsm_env.py:509-523 ; P = (p,r_s,l_d,l_q,psi_p,u_dc,deadtime)
+//      state = (u_d_buffer,u_q_buffer,epsilon,i_d,i_q,torque,omega_el) ; y = (i_d,i_q,eps)
+template <typename T> struct Pmsm {
+  static constexpr int ID = EXCENV_PMSM, S = 7, A = 2, O = 8, P = 7, NY = 3;
+  using C = Ctx<T, Pmsm>;
+  __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[3]; y[1] = st[4]; y[2] = st[2]; }
+  __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[3] = y[0]; st[4] = y[1]; st[2] = y[2]; }
+  __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&st)[S], T (&dy)[NY]) {
+    const T r_s = c.P[1], l_d = c.P[2], l_q = c.P[3], psi_p = c.P[4];
+    const T omega_el = st[6];
+    dy[0] = (u[0] + omega_el * l_q * y[1] - r_s * y[0]) / l_d;
+    dy[1] = (u[1] - omega_el * (l_d * y[0] + psi_p) - r_s * y[1]) / l_q;
+    dy[2] = omega_el;
+  }
+  // pmsm_env.py:365-375
+  __device__ static __forceinline__ T torque(T i_d, T i_q, const C& c) {
+    const T p = c.P[0], l_d = c.P[2], l_q = c.P[3], psi_p = c.P[4];
+    return T(1.5) * p * (psi_p + (l_d - l_q) * i_d) * i_q;
+  }
+  // pmsm_env.py:571-578 (wrap eps, derive torque from the new currents)
+  __device__ static __forceinline__ void post(T (&st)[S], const C& c) {
+    st[2] = wrap_angle(st[2]);
+    st[5] = torque(st[3], st[4], c);
+  }
+  // pmsm_env.py:898-919: [i_d, i_q, omega_el, torque, cos eps, sin eps, u_d_buffer, u_q_buffer]
+  __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
+    T sn, cs;
+    sincos_t(st[2], sn, cs);
+    ob[0] = normalize(st[3], c.smin[3], c.smax[3]);
+    ob[1] = normalize(st[4], c.smin[4], c.smax[4]);
+    ob[2] = normalize(st[6], c.smin[6], c.smax[6]);
+    ob[3] = normalize(st[5], c.smin[5], c.smax[5]);
+    ob[4] = cs;
+    ob[5] = sn;
+    ob[6] = normalize(st[0], c.smin[0], c.smax[0]);
+    ob[7] = normalize(st[1], c.smin[1], c.smax[1]);
+  }
+
+  // pmsm_env.py:92-102 apply_hex_constraint. The sector bits idx_k = [sin(angle(c) - 2*pi*k/3) >= 0] are taken
+  // algebraically (sin(phi - t) * |c| = beta*cos t - alpha*sin t): no atan2 / sin. The clip is continuous across
+  // sector seams, so a different pick exactly on a seam changes the result by rounding only. ROTATION_MAP is
+  // complex64 in the reference (:37-43): sqrt(3)/2 is float32-rounded in every working dtype.
+  __device__ static __forceinline__ void hex_clip(T& alpha, T& beta) {
+    const T re = alpha, im = beta;
+    const T t = T(1.7320508075688772) * re;
+    const bool i0 = im >= T(0);
+    const bool i1 = (-im - t) >= T(0);
+    const bool i2 = (t - im) >= T(0);
+    const T h = T(0.5f), q = T(0.8660254037844386f);
+    const int code = (int(i0) << 2) | (int(i1) << 1) | int(i2);
+    T rr = T(1), ri = T(0);
+    rr = (code == 5 || code == 6) ? h : rr;
+    rr = (code == 2 || code == 1) ? -h : rr;
+    rr = (code == 3) ? T(-1) : rr;
+    ri = (code == 5 || code == 1) ? q : ri;
+    ri = (code == 6 || code == 2) ? -q : ri;
+    T tr = re * rr - im * ri;
+    T ti = re * ri + im * rr;
+    const T lim_re = T(2.0 / 3.0);
+    const T lim_im = T(2.0 / 3.0) * xsqrt(T(3));
+    tr = min_nan(max_nan(tr, -lim_re), lim_re);
+    ti = min_nan(max_nan(ti, T(0)), lim_im);
+    alpha = tr * rr - ti * (-ri);
+    beta = tr * (-ri) + ti * rr;
+  }
+
+  // pmsm_env.py:594-616 constraint_denormalization with the angle `eps` as given
+  __device__ static __forceinline__ void constraint(const T (&a)[A], T eps, T omega_el, const C& c, T (&uc)[2]) {
+    const T u_dc = c.P[5];
+    const T half_dc = u_dc / T(2);
+    const T u_d = denormalize(a[0], c.amin[0], c.amax[0]);
+    const T u_q = denormalize(a[1], c.amin[1], c.amax[1]);
+    const T sc = T(1) / half_dc;
+    const T n_d = u_d * sc, n_q = u_q * sc;
+    T adv = eps + c.adv_coef * omega_el;  // step_eps(eps, deadtime+0.5, tau, omega_el) (:82-89)
+    adv = pymod_two_pi(adv);
+    adv = adv + ((adv > K<T>::pi) ? T(-2) * K<T>::pi : T(0));
+    T sn, cs;
+    sincos_t(adv, sn, cs);
+    const T sm = -sn;  // T(-adv) = [[cos, sin(-adv)], [-sin(-adv), cos]]
+    T al = cs * n_d + sm * n_q;
+    T be = (-sm) * n_d + cs * n_q;
+    hex_clip(al, be);
+    const T o_d = cs * al + sn * be;  // T(adv)
+    const T o_q = (-sn) * al + cs * be;
+    uc[0] = o_d * half_dc;
+    uc[1] = o_q * half_dc;
+  }
+};
+
+}  // namespace excenv

@@ -1,0 +1,154 @@
+// Fixed-step explicit Runge-Kutta steppers, fully unrolled at compile time so stage values live in VGPRs.
+// Euler follows diffrax.Euler.step: y1 = y0 + f(y0)*dt. RK4 / Tsit5: k_j = f(y_j,u_j)*dt,
+// y_i = y0 + sum_j a_ij k_j, y1 = y0 + sum_j b_j k_j with the sums accumulated left to right by explicit fma,
+// zero coefficients skipped — the same definition as oracle/oracle_body.inc rk_step.
+#pragma once
+#include "models.hpp"
+
+namespace excenv {
+
+template <int SOLVER> struct Tableau;
+
+template <> struct Tableau<EXCENV_RK4> {
+  static constexpr int NS = 4;
+  __host__ __device__ static constexpr double a(int s, int q) {
+    constexpr double A[4][4] = {{0, 0, 0, 0}, {0.5, 0, 0, 0}, {0.0, 0.5, 0, 0}, {0.0, 0.0, 1.0, 0}};
+    return A[s][q];
+  }
+  __host__ __device__ static constexpr double b(int q) {
+    constexpr double B[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0};
+    return B[q];
+  }
+  __host__ __device__ static constexpr bool c_is_one(int s) { return s == 3; }
+};
+
+// Tsitouras 5(4), first six stages (b7 = 0; the FSAL stage only feeds the unused error estimate).
+template <> struct Tableau<EXCENV_TSIT5> {
+  static constexpr int NS = 6;
+  __host__ __device__ static constexpr double a(int s, int q) {
+    constexpr double A[6][6] = {
+        {0, 0, 0, 0, 0, 0},
+        {0.161, 0, 0, 0, 0, 0},
+        {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
+        {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
+        {5.325864828439257, -11.74888356406283, 7.4955393428898365, -0.09249506636175525, 0, 0},
+        {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0}};
+    return A[s][q];
+  }
+  __host__ __device__ static constexpr double b(int q) {
+    constexpr double B[6] = {0.09646076681806523, 0.01, 0.4798896504144996,
+                             1.379008574103742,   -3.290069515436081, 2.324710524099774};
+    return B[q];
+  }
+  __host__ __device__ static constexpr bool c_is_one(int s) { return s == 5; }
+};
+
+// u: action held over the step; u1: action seen by stages with c_i == 1 (== u on the step path).
+template <class M, int SOLVER, typename T>
+__device__ __forceinline__ void rk_step(T (&y)[M::NY], const T (&u)[M::A], const T (&u1)[M::A], const Ctx<T, M>& c,
+                                        const T (&st)[M::S]) {
+  constexpr int NY = M::NY;
+  T dy[NY];
+  if constexpr (SOLVER == EXCENV_EULER) {
+    M::f(y, u, c, st, dy);
+#pragma unroll
+    for (int j = 0; j < NY; ++j) y[j] = y[j] + dy[j] * c.dt;
+  } else {
+    using TB = Tableau<SOLVER>;
+    constexpr int NS = TB::NS;
+    T k[NS][NY], yi[NY];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int j = 0; j < NY; ++j) {
+        T acc = T(0);
+#pragma unroll
+        for (int q = 0; q < s; ++q) {
+          const T a = T(TB::a(s, q));
+          if (a != T(0)) acc = xfma(a, k[q][j], acc);
+        }
+        yi[j] = (s == 0) ? y[j] : y[j] + acc;
+      }
+      if (TB::c_is_one(s))
+        M::f(yi, u1, c, st, dy);
+      else
+        M::f(yi, u, c, st, dy);
+#pragma unroll
+      for (int j = 0; j < NY; ++j) k[s][j] = dy[j] * c.dt;
+    }
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      T acc = T(0);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const T b = T(TB::b(q));
+        if (b != T(0)) acc = xfma(b, k[q][j], acc);
+      }
+      y[j] = y[j] + acc;
+    }
+  }
+}
+
+// One reference `step` on the carried state (CoreEnvironment.step core_env.py:393-425; PMSM.step pmsm_env.py:851-883).
+template <class M, int SOLVER, typename T>
+__device__ __forceinline__ void env_step(T (&st)[M::S], const T (&a)[M::A], const Ctx<T, M>& c) {
+  T u[M::A];
+  if constexpr (M::ID == EXCENV_PMSM) {
+    T uc[2];
+    M::constraint(a, st[2], st[6], c, uc);
+    if (c.P[6] > T(0)) {  // deadtime: apply the buffered voltage, buffer the new one
+      u[0] = st[0]; u[1] = st[1];
+      st[0] = uc[0]; st[1] = uc[1];
+    } else {
+      u[0] = uc[0]; u[1] = uc[1];
+    }
+  } else {
+    u[0] = denormalize(a[0], c.amin[0], c.amax[0]);
+  }
+  T y[M::NY];
+  M::get_y(st, y);
+  rk_step<M, SOLVER>(y, u, u, c, st);
+  M::set_y(st, y);
+  M::post(st, c);
+}
+
+// Extra carried values for the reference's sim_ahead structure (only PMSM needs any).
+template <typename T> struct AheadAux {
+  T eps0, buf0[2], prev_clip[2];
+};
+
+// One solver step of the raw ODE state, reference _ode_solver_simulate_ahead structure (SEM_AHEAD):
+// no wrap / clip of the carried state; PMSM clips with the predicted angle eps0 + (k*tau)*omega
+// (pmsm_env.py:719-722) and applies actions_dead[k] (:766-777).
+template <class M, int SOLVER, typename T>
+__device__ __forceinline__ void env_advance_raw(T (&st)[M::S], const T (&a)[M::A], const T (&a1)[M::A], int64_t k,
+                                                int64_t k1, const Ctx<T, M>& c, AheadAux<T>& aux) {
+  T u[M::A], u1[M::A];
+  if constexpr (M::ID == EXCENV_PMSM) {
+    T uc[2];
+    M::constraint(a, aux.eps0 + (T(k) * c.env_tau) * st[6], st[6], c, uc);
+    if (c.P[6] > T(0)) {
+      u[0] = aux.prev_clip[0]; u[1] = aux.prev_clip[1];
+      u1[0] = (k1 == k) ? u[0] : uc[0];
+      u1[1] = (k1 == k) ? u[1] : uc[1];
+    } else {
+      u[0] = uc[0]; u[1] = uc[1];
+      if constexpr (SOLVER != EXCENV_EULER) {
+        M::constraint(a1, aux.eps0 + (T(k1) * c.env_tau) * st[6], st[6], c, u1);
+      } else {
+        u1[0] = u[0]; u1[1] = u[1];
+      }
+    }
+    aux.prev_clip[0] = uc[0];
+    aux.prev_clip[1] = uc[1];
+  } else {
+    u[0] = denormalize(a[0], c.amin[0], c.amax[0]);
+    u1[0] = denormalize(a1[0], c.amin[0], c.amax[0]);
+  }
+  T y[M::NY];
+  M::get_y(st, y);
+  rk_step<M, SOLVER>(y, u, u1, c, st);
+  M::set_y(st, y);
+}
+
+}  // namespace excenv

@@ -1,0 +1,23 @@
+"""MI355X-native batched ODE stepping behind exciting-environments' vmap_step / vmap_sim_ahead API.
+
+Usage mirrors the reference package (README.md:15-33):
+
+    import exciting_environments_amd as excenvs
+    from exciting_environments_amd import EnvironmentRegistry
+    env = EnvironmentRegistry.PENDULUM.make(batch_size=5, tau=2e-2)
+    obs, state = env.vmap_reset()
+    obs, state = env.vmap_step(state, actions)            # one fused HIP launch
+    observations, states, last_state = env.vmap_sim_ahead(state, actions, env.tau, env.tau)  # one persistent launch
+"""
+from .core_env import CoreEnvironment
+from .envs import Acrobot, CartPole, FluidTank, MassSpringDamper, MotorVariant, Pendulum, PMSM
+from .registration import EnvironmentRegistry
+from .solvers import Euler, RK4, Tsit5
+from .utils import MinMaxNormalization, dump_sim_properties_to_json, load_sim_properties_from_json
+from . import tree, utils
+
+__all__ = [
+    "CoreEnvironment", "Acrobot", "CartPole", "FluidTank", "MassSpringDamper", "Pendulum", "PMSM", "MotorVariant",
+    "EnvironmentRegistry", "Euler", "RK4", "Tsit5", "MinMaxNormalization", "dump_sim_properties_to_json",
+    "load_sim_properties_from_json", "tree", "utils",
+]

@@ -1,0 +1,173 @@
+"""ctypes binding of libexcenv_hip.so (C ABI: include/excenv.h).
+
+This is the only compute backend of the package. There is no CPU or PyTorch fallback: if the
+shared library is missing, or no HIP device is present when a kernel entry point is called, the
+call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import torch
+
+MAX_STATE, MAX_ACTION, MAX_STATIC, MAX_CONTROL = 8, 2, 9, 8
+LAYOUT_ENV_MAJOR, LAYOUT_LANE_MAJOR = 0, 1
+SEM_STEP, SEM_AHEAD = 0, 1
+F32, F64 = 0, 1
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libexcenv_hip.so")
+
+
+class Param(ctypes.Structure):
+    _fields_ = [("value", ctypes.c_double), ("per_env", ctypes.c_void_p)]
+
+
+class Props(ctypes.Structure):
+    _fields_ = [
+        ("static_params", Param * MAX_STATIC),
+        ("state_min", Param * MAX_STATE),
+        ("state_max", Param * MAX_STATE),
+        ("action_min", Param * MAX_ACTION),
+        ("action_max", Param * MAX_ACTION),
+    ]
+
+
+class Control(ctypes.Structure):
+    _fields_ = [
+        ("n_control", ctypes.c_int32),
+        ("control_idx", ctypes.c_int32 * MAX_CONTROL),
+        ("reference", ctypes.c_void_p * MAX_CONTROL),
+    ]
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def lib():
+    """Load libexcenv_hip.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C exciting-environments_amd/csrc). "
+                "There is no CPU fallback."
+            )
+        l = ctypes.CDLL(_LIB_PATH)
+        l.excenv_last_error.restype = ctypes.c_char_p
+        l.excenv_abi_version.restype = ctypes.c_int
+        l.excenv_step_bytes.restype = ctypes.c_int64
+        l.excenv_sim_ahead_bytes.restype = ctypes.c_int64
+        for fn in ("excenv_step", "excenv_sim_ahead", "excenv_env_dims", "excenv_probe_math", "excenv_set_tuning"):
+            getattr(l, fn).restype = ctypes.c_int
+        if l.excenv_abi_version() != 1:
+            raise ImportError("libexcenv_hip.so: ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().excenv_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def dtype_id(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.float64:
+        return F64
+    raise TypeError(f"unsupported dtype {dtype}: the kernels compute in float32 or float64")
+
+
+def _require_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: tensors must live on a HIP device (got {t.device}). The batched ODE kernels have no CPU fallback."
+        )
+
+
+def _ptrs(tensors: Sequence[torch.Tensor]):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def env_dims(env_id: int):
+    S, A, O, P = (ctypes.c_int32() for _ in range(4))
+    _check(lib().excenv_env_dims(env_id, ctypes.byref(S), ctypes.byref(A), ctypes.byref(O), ctypes.byref(P)), "excenv_env_dims")
+    return S.value, A.value, O.value, P.value
+
+
+def step_bytes(env_id: int, dtype: torch.dtype) -> int:
+    return int(lib().excenv_step_bytes(env_id, dtype_id(dtype)))
+
+
+def sim_ahead_bytes(env_id: int, dtype: torch.dtype, with_state_traj: bool = True) -> int:
+    return int(lib().excenv_sim_ahead_bytes(env_id, dtype_id(dtype), int(with_state_traj)))
+
+
+def set_tuning(key: int, value: int) -> int:
+    return int(lib().excenv_set_tuning(key, value))
+
+
+def make_control(control_idx: Sequence[int], refs: Sequence[torch.Tensor]) -> Optional[Control]:
+    if not control_idx:
+        return None
+    c = Control()
+    c.n_control = len(control_idx)
+    for j, (f, r) in enumerate(zip(control_idx, refs)):
+        c.control_idx[j] = f
+        c.reference[j] = r.data_ptr()
+    return c
+
+
+def step(env_id, solver_id, dtype, B, props: Props, control: Optional[Control], tau: float,
+         state_in: Sequence[torch.Tensor], action: torch.Tensor, state_out: Sequence[torch.Tensor],
+         obs: torch.Tensor):
+    _require_device(action, "vmap_step")
+    with torch.cuda.device(action.device):
+        stream = torch.cuda.current_stream(action.device).cuda_stream
+        rc = lib().excenv_step(
+            ctypes.c_int(env_id), ctypes.c_int(solver_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B),
+            ctypes.byref(props), ctypes.byref(control) if control is not None else None, ctypes.c_double(tau),
+            _ptrs(state_in), ctypes.c_void_p(action.data_ptr()), _ptrs(state_out), ctypes.c_void_p(obs.data_ptr()),
+            ctypes.c_void_p(stream),
+        )
+    _check(rc, "excenv_step")
+
+
+def sim_ahead(env_id, solver_id, dtype, B, K, substeps, props: Props, control: Optional[Control],
+              obs_stepsize: float, env_tau: float, state_in: Sequence[torch.Tensor], actions: torch.Tensor,
+              action_layout: int, obs_traj: torch.Tensor, state_traj: Optional[Sequence[torch.Tensor]],
+              traj_layout: int, last_state: Sequence[torch.Tensor], semantics: int):
+    _require_device(obs_traj, "vmap_sim_ahead")
+    with torch.cuda.device(obs_traj.device):
+        stream = torch.cuda.current_stream(obs_traj.device).cuda_stream
+        rc = lib().excenv_sim_ahead(
+            ctypes.c_int(env_id), ctypes.c_int(solver_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B),
+            ctypes.c_int64(K), ctypes.c_int32(substeps), ctypes.byref(props),
+            ctypes.byref(control) if control is not None else None, ctypes.c_double(obs_stepsize),
+            ctypes.c_double(env_tau), _ptrs(state_in), ctypes.c_void_p(actions.data_ptr() if K > 0 else None),
+            ctypes.c_int(action_layout), ctypes.c_void_p(obs_traj.data_ptr()),
+            _ptrs(state_traj) if state_traj is not None else None, ctypes.c_int(traj_layout), _ptrs(last_state),
+            ctypes.c_int(semantics), ctypes.c_void_p(stream),
+        )
+    _check(rc, "excenv_sim_ahead")
+
+
+def probe_math(which: int, x: torch.Tensor) -> torch.Tensor:
+    _require_device(x, "probe_math")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = lib().excenv_probe_math(ctypes.c_int(which), ctypes.c_int(dtype_id(x.dtype)), ctypes.c_int64(x.numel()),
+                                     ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                     ctypes.c_void_p(stream))
+    _check(rc, "excenv_probe_math")
+    return out

@@ -1,0 +1,490 @@
+"""Core batched runtime — host-side mirror of reference exciting_environments/core_env.py.
+
+Same class, method names, argument meaning, return shapes and error behaviour as the reference's
+``CoreEnvironment`` for the batched ODE hot path; the arithmetic of ``vmap_step`` / ``vmap_sim_ahead``
+(and their single-env forms) runs in hand-written HIP kernels behind the C ABI of ``include/excenv.h``.
+Arrays are ``torch`` tensors on the HIP device (``jax`` is not part of this stack); pytrees are plain
+dataclasses (helpers in ``tree.py``).
+
+Differences from the reference that a caller can observe are listed in DESIGN.md ("Deviations").
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from abc import ABC
+from dataclasses import dataclass, fields, is_dataclass, replace
+from typing import Any, Optional
+
+import numpy as np
+import torch
+
+from . import _native
+from .solvers import Euler, _Solver
+from .tree import tree_structure
+
+
+def _is_array(x) -> bool:
+    return isinstance(x, (torch.Tensor, np.ndarray))
+
+
+def _is_scalar(x) -> bool:
+    if isinstance(x, (bool, int, float, np.generic)):
+        return True
+    return _is_array(x) and x.ndim == 0
+
+
+class CoreEnvironment(ABC):
+    """Core structure of the provided environments (reference core_env.py:15-57).
+
+    The simulated systems are physical state-space models dx/dt = f(x(t), u(t)); outputs are
+    discretised with a fixed-step ODE solver. Sub-classes define the field names of the physical
+    state / action / static parameters; the vector field itself lives in the HIP kernels.
+    """
+
+    # set by sub-classes
+    ENV_ID: int = -1
+    STATE_FIELDS: tuple = ()
+    ACTION_FIELDS: tuple = ()
+    PARAM_FIELDS: tuple = ()
+    DEFAULT_NORM_STATE: tuple = ()  # normalised default reset state (rng=None)
+    PhysicalState: Any = None
+    Action: Any = None
+    StaticParams: Any = None
+    Additions: Any = None
+
+    @dataclass
+    class State:
+        """The state of the environment (core_env.py:236-243)."""
+
+        physical_state: Any
+        PRNGKey: Any
+        additions: Any
+        reference: Any
+
+    @dataclass
+    class EnvProperties:
+        """The properties of the environment that stay constant during simulation (core_env.py:245-251)."""
+
+        physical_normalizations: Any
+        action_normalizations: Any
+        static_params: Any
+
+    def __init__(self, batch_size: int, env_properties, tau: float = 1e-4, solver=Euler(), dtype=torch.float32,
+                 device=None):
+        """core_env.py:36-57. ``dtype`` replaces the reference's process-global ``jax_enable_x64`` switch;
+        ``device`` defaults to the current HIP device (CPU tensors are only good for construction / reset)."""
+        if not isinstance(solver, _Solver):
+            raise TypeError(
+                f"solver must be one of exciting_environments_amd.Euler()/RK4()/Tsit5(), got {type(solver)}"
+            )
+        _native.dtype_id(dtype)
+        self.batch_size = batch_size
+        self.tau = tau
+        self._solver = solver
+        self.dtype = dtype
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        self.env_properties = env_properties
+        self.in_axes_env_properties = self.create_in_axes_dataclass(env_properties)
+        self.action_dim = len(fields(self.Action))
+        self.physical_state_dim = len(fields(self.PhysicalState))
+        # "lane_major": trajectories are [K+1, O, B] buffers returned as [B, K+1, O] views (coalesced kernel
+        # accesses); "env_major": contiguous [B, K+1, O] like the reference's row-major jnp arrays.
+        self.traj_layout = "lane_major"
+        # "ahead": structure of the reference's _ode_solver_simulate_ahead; "step": K exact `step`s.
+        self.sim_ahead_semantics = "ahead"
+        self._packed_props = None
+
+    # ------------------------------------------------------------------ properties plumbing
+    def create_in_axes_dataclass(self, dataclass_obj):
+        """core_env.py:253-277: 0 for leaves batched over batch_size, None for broadcast leaves."""
+        out = {}
+        for f in fields(dataclass_obj):
+            name = f.name
+            value = getattr(dataclass_obj, name)
+            if value is None:
+                out[name] = None
+            elif isinstance(value, list):
+                raise ValueError(
+                    f'Passed env property "{name}" needs to be a jnp.array to have different setting per batch, but list is given.'
+                )
+            elif is_dataclass(value):
+                out[name] = self.create_in_axes_dataclass(value)
+            elif _is_scalar(value):
+                out[name] = None
+            elif _is_array(value):
+                out[name] = 0 if value.shape[0] == self.batch_size else None
+            else:
+                raise ValueError(
+                    f'Passed env property "{name}" needs to be a scalar, jnp.array or jdc.pytree_dataclass, but {type(value)} is given.'
+                )
+        return replace(dataclass_obj, **out)
+
+    def _leaf(self, x):
+        """Property leaf -> Python float (broadcast) or [B] tensor of the working dtype on the device."""
+        if _is_array(x) and x.ndim >= 1:
+            t = torch.as_tensor(x).to(device=self.device, dtype=self.dtype)
+            return t
+        if isinstance(x, torch.Tensor):
+            return float(x.item())
+        return float(x)
+
+    def _pack_props(self, env_properties, B: int):
+        """EnvProperties -> excenv_props_t (+ the device tensors it points into, kept alive by the caller)."""
+        keep = []
+        p = _native.Props()
+
+        def put(param, value, what):
+            v = self._leaf(value)
+            if isinstance(v, torch.Tensor):
+                if v.shape[0] != B or v.ndim != 1:
+                    if v.numel() == 1:
+                        param.value, param.per_env = float(v.reshape(()).item()), None
+                        return
+                    raise ValueError(f"env property {what} has shape {tuple(v.shape)}; expected a scalar or ({B},)")
+                v = v.contiguous()
+                keep.append(v)
+                param.value, param.per_env = float("nan"), v.data_ptr()
+            else:
+                param.value, param.per_env = v, None
+
+        for j, n in enumerate(self.PARAM_FIELDS):
+            put(p.static_params[j], getattr(env_properties.static_params, n), f"static_params.{n}")
+        for j, n in enumerate(self.STATE_FIELDS):
+            nm = getattr(env_properties.physical_normalizations, n)
+            put(p.state_min[j], nm.min, f"physical_normalizations.{n}.min")
+            put(p.state_max[j], nm.max, f"physical_normalizations.{n}.max")
+        for j, n in enumerate(self.ACTION_FIELDS):
+            nm = getattr(env_properties.action_normalizations, n)
+            put(p.action_min[j], nm.min, f"action_normalizations.{n}.min")
+            put(p.action_max[j], nm.max, f"action_normalizations.{n}.max")
+        return p, keep
+
+    def _props_for(self, env_properties, B: int):
+        if env_properties is self.env_properties and B == self.batch_size:
+            if self._packed_props is None:
+                self._packed_props = self._pack_props(env_properties, B)
+            return self._packed_props
+        return self._pack_props(env_properties, B)
+
+    def _t(self, x, shape=None):
+        t = torch.as_tensor(x).to(device=self.device, dtype=self.dtype)
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            t = t.expand(shape)
+        return t.contiguous()
+
+    def _norm_leaf(self, x):
+        return self._leaf(x)
+
+    # ------------------------------------------------------------------ normalisation (torch, elementwise)
+    def normalize_state(self, state, env_properties):
+        """core_env.py:292-314."""
+        pn = env_properties.physical_normalizations
+        phys, ref = {}, {}
+        for n in self.STATE_FIELDS:
+            nm = getattr(pn, n)
+            lo, hi = self._norm_leaf(nm.min), self._norm_leaf(nm.max)
+            phys[n] = 2 * (getattr(state.physical_state, n) - lo) / (hi - lo) - 1
+            ref[n] = 2 * (getattr(state.reference, n) - lo) / (hi - lo) - 1
+        return replace(state, physical_state=self.PhysicalState(**phys), reference=self.PhysicalState(**ref))
+
+    def denormalize_state(self, norm_state, env_properties):
+        """core_env.py:316-340."""
+        pn = env_properties.physical_normalizations
+        phys, ref = {}, {}
+        for n in self.STATE_FIELDS:
+            nm = getattr(pn, n)
+            lo, hi = self._norm_leaf(nm.min), self._norm_leaf(nm.max)
+            phys[n] = (getattr(norm_state.physical_state, n) + 1) / 2 * (hi - lo) + lo
+            ref[n] = (getattr(norm_state.reference, n) + 1) / 2 * (hi - lo) + lo
+        return replace(norm_state, physical_state=self.PhysicalState(**phys), reference=self.PhysicalState(**ref))
+
+    def denormalize_action(self, action_norm, env_properties):
+        """core_env.py:342-359 (last axis = action components)."""
+        an = env_properties.action_normalizations
+        cols = []
+        for i, n in enumerate(self.ACTION_FIELDS):
+            nm = getattr(an, n)
+            lo, hi = self._norm_leaf(nm.min), self._norm_leaf(nm.max)
+            cols.append((action_norm[..., i] + 1) / 2 * (hi - lo) + lo)
+        return torch.stack(cols, dim=-1)
+
+    # ------------------------------------------------------------------ state construction
+    def _nan(self, shape):
+        return torch.full(shape, float("nan"), dtype=self.dtype, device=self.device)
+
+    def _additions(self, shape, active: bool):
+        return self.Additions(solver_state=None,
+                              active_solver_state=torch.full(shape, active, dtype=torch.bool, device=self.device))
+
+    def _random_norm_state(self, rng, shape):
+        """Random normalised initial state (e.g. pendulum_env.py:270-276). `rng` is a torch.Generator or an int
+        seed; JAX's Threefry bit-stream is not reproduced."""
+        gen = rng
+        if not isinstance(rng, torch.Generator):
+            gen = torch.Generator(device=self.device)
+            gen.manual_seed(int(rng))
+        lo = 0.0 if self.ENV_ID == 4 else -1.0  # FluidTank draws the height from [0, 1) (fluid_tank_env.py:226)
+        return {
+            n: (torch.rand(shape, generator=gen, dtype=self.dtype, device=self.device) * (1.0 - lo) + lo)
+            for n in self.STATE_FIELDS
+        }
+
+    def _init_state(self, env_properties, rng, shape):
+        if rng is None:
+            norm = {n: torch.full(shape, v, dtype=self.dtype, device=self.device)
+                    for n, v in zip(self.STATE_FIELDS, self.DEFAULT_NORM_STATE)}
+        else:
+            norm = self._random_norm_state(rng, shape)
+        ref = {n: self._nan(shape) for n in self.STATE_FIELDS}
+        norm_state = self.State(physical_state=self.PhysicalState(**norm), PRNGKey=self._nan(shape),
+                                additions=self._additions(shape, False), reference=self.PhysicalState(**ref))
+        return self.denormalize_state(norm_state, env_properties)
+
+    def init_state(self, env_properties, rng=None, vmap_helper=None):
+        """Default (rng=None) or random initial state for one environment (e.g. pendulum_env.py:261-295)."""
+        return self._init_state(env_properties, rng, ())
+
+    def vmap_init_state(self, rng=None):
+        """core_env.py:649-662."""
+        return self._init_state(self.env_properties, rng, (self.batch_size,))
+
+    def generate_observation(self, state, env_properties):
+        """Normalised physical state (+ normalised reference for each name in control_state), stacked on the last
+        axis (e.g. pendulum_env.py:311-329). Elementwise torch ops; the step kernels fuse their own copy."""
+        ns = self.normalize_state(state, env_properties)
+        cols = [getattr(ns.physical_state, n) for n in self.STATE_FIELDS]
+        cols += [getattr(ns.reference, n) for n in self.control_state]
+        return torch.stack(torch.broadcast_tensors(*cols), dim=-1)
+
+    def generate_state_from_observation(self, obs, env_properties, key=None):
+        """e.g. pendulum_env.py:331-364."""
+        obs = self._t(obs)
+        shape = tuple(obs.shape[:-1])
+        S = len(self.STATE_FIELDS)
+        phys = {n: obs[..., j] for j, n in enumerate(self.STATE_FIELDS)}
+        ref = {n: self._nan(shape) for n in self.STATE_FIELDS}
+        for pos, n in enumerate(self.control_state):
+            ref[n] = obs[..., S + pos]
+        norm_state = self.State(physical_state=self.PhysicalState(**phys),
+                                PRNGKey=self._nan(shape) if key is None else key,
+                                additions=self._additions(shape, False), reference=self.PhysicalState(**ref))
+        return self.denormalize_state(norm_state, env_properties)
+
+    def vmap_generate_state_from_observation(self, obs, key=None):
+        """core_env.py:689-705."""
+        return self.generate_state_from_observation(obs, self.env_properties, key)
+
+    # ------------------------------------------------------------------ reset
+    def reset(self, env_properties, rng=None, initial_state=None, vmap_helper=None):
+        """core_env.py:361-391."""
+        if initial_state is not None:
+            assert tree_structure(self.init_state(env_properties)) == tree_structure(
+                initial_state
+            ), "initial_state should have the same dataclass structure as init_state()"
+            state = initial_state
+        else:
+            state = self.init_state(env_properties, rng)
+        obs = self.generate_observation(state, env_properties)
+        return obs, state
+
+    def vmap_reset(self, rng=None, initial_state=None):
+        """core_env.py:664-687."""
+        if initial_state is not None:
+            assert tree_structure(self.vmap_init_state()) == tree_structure(
+                initial_state
+            ), "initial_state should have the same dataclass structure as self.vmap_init_state()"
+            state = initial_state
+        else:
+            state = self.vmap_init_state(rng)
+        obs = self.generate_observation(state, self.env_properties)
+        return obs, state
+
+    # ------------------------------------------------------------------ the hot path
+    def _control(self, state, shape):
+        idx = [self.STATE_FIELDS.index(n) for n in self.control_state]
+        refs = [self._t(getattr(state.reference, n), shape) for n in self.control_state]
+        return _native.make_control(idx, refs), refs
+
+    def _run_step(self, state, action, env_properties, B):
+        S, O = self.physical_state_dim, self._obs_dim()
+        props, keep = self._props_for(env_properties, B)
+        st_in = [self._t(getattr(state.physical_state, n), (B,)) for n in self.STATE_FIELDS]
+        act = self._t(action, (B, self.action_dim))
+        control, refs = self._control(state, (B,))
+        st_out = [torch.empty(B, dtype=self.dtype, device=self.device) for _ in range(S)]
+        obs = torch.empty((B, O), dtype=self.dtype, device=self.device)
+        _native.step(self.ENV_ID, self._solver.id, self.dtype, B, props, control, float(self.tau), st_in, act,
+                     st_out, obs)
+        return obs, st_out
+
+    def _obs_dim(self):
+        return _native.env_dims(self.ENV_ID)[2] + len(self.control_state)
+
+    def step(self, state, action_norm, env_properties):
+        """One simulation step of a single environment (core_env.py:393-425)."""
+        action_norm = torch.as_tensor(action_norm)
+        assert tuple(action_norm.shape) == (self.action_dim,), (
+            "The action needs to be of shape (action_dim,) which is "
+            + f"{(self.action_dim,)}, but {tuple(action_norm.shape)} is given"
+        )
+        physical_state_shape = self._phys_shape(state.physical_state)
+        assert physical_state_shape == (self.physical_state_dim,), (
+            "The physical state needs to be of shape (physical_state_dim,) which is "
+            + f"{(self.physical_state_dim,)}, but {physical_state_shape} is given"
+        )
+        obs, st_out = self._run_step(state, action_norm.reshape(1, -1), env_properties, 1)
+        new_phys = self.PhysicalState(**{n: t.reshape(()) for n, t in zip(self.STATE_FIELDS, st_out)})
+        new_state = replace(state, physical_state=new_phys, additions=self._additions((), True))
+        return obs[0], new_state
+
+    def vmap_step(self, state, action):
+        """One simulation step of all batch_size environments (core_env.py:533-569)."""
+        action = torch.as_tensor(action)
+        assert tuple(action.shape) == (self.batch_size, self.action_dim), (
+            "The action needs to be of shape (batch_size, action_dim) which is "
+            + f"{(self.batch_size, self.action_dim)}, but {tuple(action.shape)} is given"
+        )
+        physical_state_shape = self._phys_shape(state.physical_state)
+        assert physical_state_shape == (self.batch_size, self.physical_state_dim), (
+            "The physical state needs to be of shape (batch_size, physical_state_dim) which is "
+            + f"{(self.batch_size, self.physical_state_dim)}, but {physical_state_shape} is given"
+        )
+        obs, st_out = self._run_step(state, action, self.env_properties, self.batch_size)
+        new_phys = self.PhysicalState(**dict(zip(self.STATE_FIELDS, st_out)))
+        new_state = replace(state, physical_state=new_phys, additions=self._additions((self.batch_size,), True))
+        return obs, new_state
+
+    def _phys_shape(self, physical_state):
+        leaves = [torch.as_tensor(getattr(physical_state, n)) for n in self.STATE_FIELDS]
+        return tuple(leaves[0].shape) + (len(leaves),)
+
+    @staticmethod
+    def _n_substeps(K, obs_stepsize, action_stepsize):
+        """Number of solver steps per action. The reference saves 1 + int(t1 / obs_stepsize) rows with
+        t1 = action_stepsize * K evaluated in Python doubles (pendulum_env.py:222-225)."""
+        ratio = action_stepsize / obs_stepsize
+        sub = int(round(ratio))
+        if sub < 1 or abs(ratio - sub) > 1e-9 * max(1.0, ratio):
+            raise ValueError("action_stepsize must be an integer multiple of obs_stepsize "
+                             f"(got {action_stepsize} / {obs_stepsize})")
+        n_ref = 1 + int((action_stepsize * K) / obs_stepsize)
+        if n_ref != K * sub + 1:
+            warnings.warn(
+                f"the reference's 1 + int(t1/obs_stepsize) evaluates to {n_ref} rows for these step sizes "
+                f"(floating-point floor); returning the intended {K * sub + 1} rows", RuntimeWarning)
+        return sub
+
+    def _run_sim_ahead(self, init_state, actions, env_properties, obs_stepsize, action_stepsize, B):
+        S, A, OW = self.physical_state_dim, self.action_dim, self._obs_dim()
+        actions = torch.as_tensor(actions)
+        K = actions.shape[1]
+        sub = self._n_substeps(K, obs_stepsize, action_stepsize)
+        N = K * sub
+        props, keep = self._props_for(env_properties, B)
+        st_in = [self._t(getattr(init_state.physical_state, n), (B,)) for n in self.STATE_FIELDS]
+        control, refs = self._control(init_state, (B,))
+
+        if actions.device != self.device or actions.dtype != self.dtype:
+            actions = actions.to(device=self.device, dtype=self.dtype)
+        if K > 0 and B > 0 and tuple(actions.stride()) == (1, A * B, B):
+            a_layout = _native.LAYOUT_LANE_MAJOR  # a [K, A, B] buffer viewed as [B, K, A]
+        else:
+            actions = actions.contiguous()
+            a_layout = _native.LAYOUT_ENV_MAJOR
+
+        if self.traj_layout == "lane_major":
+            obs_buf = torch.empty((N + 1, OW, B), dtype=self.dtype, device=self.device)
+            st_buf = [torch.empty((N + 1, B), dtype=self.dtype, device=self.device) for _ in range(S)]
+            t_layout = _native.LAYOUT_LANE_MAJOR
+            observations = obs_buf.permute(2, 0, 1)
+            st_views = [b.t() for b in st_buf]
+        elif self.traj_layout == "env_major":
+            obs_buf = torch.empty((B, N + 1, OW), dtype=self.dtype, device=self.device)
+            st_buf = [torch.empty((B, N + 1), dtype=self.dtype, device=self.device) for _ in range(S)]
+            t_layout = _native.LAYOUT_ENV_MAJOR
+            observations, st_views = obs_buf, st_buf
+        else:
+            raise ValueError(f"traj_layout must be 'lane_major' or 'env_major', got {self.traj_layout!r}")
+        last = [torch.empty(B, dtype=self.dtype, device=self.device) for _ in range(S)]
+        sem = {"ahead": _native.SEM_AHEAD, "step": _native.SEM_STEP}[self.sim_ahead_semantics]
+        _native.sim_ahead(self.ENV_ID, self._solver.id, self.dtype, B, K, sub, props, control, float(obs_stepsize),
+                          float(self.tau), st_in, actions, a_layout, obs_buf, st_buf, t_layout, last, sem)
+        return observations, st_views, last, N
+
+    def _traj_state(self, init_state, st_views, lead_shape, N):
+        """Rebuild the State pytree of a trajectory: reference / PRNGKey broadcast along the saved rows,
+        active_solver_state all True (e.g. pendulum_env.py:243-259)."""
+        shape = lead_shape + (N + 1,)
+        phys = self.PhysicalState(**dict(zip(self.STATE_FIELDS, st_views)))
+        ref = self.PhysicalState(**{
+            n: self._t(getattr(init_state.reference, n)).reshape(lead_shape + (1,)).expand(shape)
+            for n in self.STATE_FIELDS
+        })
+        key = self._t(init_state.PRNGKey).reshape(lead_shape + (1,)).expand(shape)
+        return self.State(physical_state=phys, PRNGKey=key, additions=self._additions(shape, True), reference=ref)
+
+    def sim_ahead(self, init_state, actions, env_properties, obs_stepsize, action_stepsize):
+        """Trajectory of a single environment (core_env.py:427-488): actions (n_action_steps, action_dim) ->
+        observations (n+1, obs_dim), states, last_state."""
+        actions = torch.as_tensor(actions)
+        assert actions.ndim == 2, "The actions need to have two dimensions: (n_action_steps, action_dim)"
+        assert (
+            actions.shape[-1] == self.action_dim
+        ), f"The last dimension does not correspond to the action dim which is {self.action_dim}, but {actions.shape[-1]} is given"
+        init_physical_state_shape = self._phys_shape(init_state.physical_state)
+        assert init_physical_state_shape == (self.physical_state_dim,), (
+            "The initial physical state needs to be of shape (env.physical_state_dim,) which is "
+            + f"{(self.physical_state_dim,)}, but {init_physical_state_shape} is given"
+        )
+        obs, st_views, last, N = self._run_sim_ahead(init_state, actions[None], env_properties, obs_stepsize,
+                                                     action_stepsize, 1)
+        states = self._traj_state(init_state, [v[0] for v in st_views], (), N)
+        last_state = replace(init_state, physical_state=self.PhysicalState(
+            **{n: t.reshape(()) for n, t in zip(self.STATE_FIELDS, last)}), additions=self._additions((), True))
+        return obs[0], states, last_state
+
+    def vmap_sim_ahead(self, init_state, actions, obs_stepsize, action_stepsize):
+        """Trajectories of all batch_size environments in one persistent kernel launch (core_env.py:571-616):
+        actions (batch_size, n_action_steps, action_dim) -> observations (batch_size, n+1, obs_dim), states with
+        leaves (batch_size, n+1), last_state with leaves (batch_size,)."""
+        assert (
+            obs_stepsize <= action_stepsize
+        ), "The action stepsize should be greater or equal to the observation stepsize."
+        actions = torch.as_tensor(actions)
+        assert actions.ndim == 3, "The actions need to have three dimensions: (batch_size, n_action_steps, action_dim)"
+        assert (
+            actions.shape[0] == self.batch_size
+        ), f"The first dimension does not correspond to the batch size which is {self.batch_size}, but {actions.shape[0]} is given"
+        assert (
+            actions.shape[-1] == self.action_dim
+        ), f"The last dimension does not correspond to the action dim which is {self.action_dim}, but {actions.shape[-1]} is given"
+        init_physical_state_shape = self._phys_shape(init_state.physical_state)
+        assert init_physical_state_shape == (self.batch_size, self.physical_state_dim), (
+            "The initial physical state needs to be of shape (batch_size, physical_state_dim,) which is "
+            + f"{(self.batch_size, self.physical_state_dim)}, but {init_physical_state_shape} is given"
+        )
+        B = self.batch_size
+        obs, st_views, last, N = self._run_sim_ahead(init_state, actions, self.env_properties, obs_stepsize,
+                                                     action_stepsize, B)
+        states = self._traj_state(init_state, st_views, (B,), N)
+        last_state = replace(init_state, physical_state=self.PhysicalState(**dict(zip(self.STATE_FIELDS, last))),
+                             additions=self._additions((B,), True))
+        return obs, states, last_state
+
+    def new_actions_buffer(self, n_action_steps: int):
+        """A (batch_size, n_action_steps, action_dim) tensor whose memory is lane-major ([K, A, B]); filling this
+        and passing it to vmap_sim_ahead lets the kernel read actions fully coalesced with no transposition."""
+        buf = torch.empty((n_action_steps, self.action_dim, self.batch_size), dtype=self.dtype, device=self.device)
+        return buf.permute(2, 0, 1)
+
+    # ------------------------------------------------------------------ descriptions
+    @property
+    def obs_description(self):
+        return np.hstack([np.array(list(self.STATE_FIELDS)), np.array([n + "_ref" for n in self.control_state])])
+
+    @property
+    def action_description(self):
+        return np.array(list(self.ACTION_FIELDS))

@@ -1,0 +1,339 @@
+"""The six ODE environments — host-side mirrors of the reference classes
+(pendulum/pendulum_env.py, mass_spring_damper/mass_spring_damper_env.py, cart_pole/cart_pole_env.py,
+acrobot/acrobot_env.py, fluid_tank/fluid_tank_env.py, pmsm/pmsm_env.py): same constructor keywords,
+defaults, dataclass field names and orders. The vector fields themselves are HIP device code
+(csrc/models.hpp)."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, make_dataclass, replace
+from enum import Enum
+from typing import Any, Callable
+
+import numpy as np
+import torch
+
+from .core_env import CoreEnvironment
+from .solvers import Euler
+from .utils import MinMaxNormalization
+
+
+def _dc(name, field_names, doc):
+    cls = make_dataclass(name, [(f, Any) for f in field_names])
+    cls.__doc__ = doc
+    return cls
+
+
+@dataclass
+class _Additions:
+    """Dataclass containing additional information for simulation (e.g. pendulum_env.py:123-128). The fixed-step
+    kernels carry no solver state, so `solver_state` is always None."""
+
+    solver_state: Any
+    active_solver_state: Any
+
+
+class _SimpleEnv(CoreEnvironment):
+    """Shared constructor of the five single-action environments (e.g. pendulum_env.py:52-114)."""
+
+    DEFAULT_PHYSICAL_NORMALIZATIONS: dict = {}
+    DEFAULT_ACTION_NORMALIZATIONS: dict = {}
+    DEFAULT_STATIC_PARAMS: dict = {}
+    DEFAULT_BATCH_SIZE = 8
+    DEFAULT_TAU = 1e-4
+    Additions = _Additions
+
+    def __init__(self, batch_size: int = None, physical_normalizations: dict = None,
+                 action_normalizations: dict = None, soft_constraints: Callable = None, static_params: dict = None,
+                 control_state: list = None, solver=Euler(), tau: float = None, dtype=torch.float32, device=None):
+        if batch_size is None:
+            batch_size = self.DEFAULT_BATCH_SIZE
+        if tau is None:
+            tau = self.DEFAULT_TAU
+        if not physical_normalizations:
+            physical_normalizations = {k: MinMaxNormalization(*v) for k, v in self.DEFAULT_PHYSICAL_NORMALIZATIONS.items()}
+        if not action_normalizations:
+            action_normalizations = {k: MinMaxNormalization(*v) for k, v in self.DEFAULT_ACTION_NORMALIZATIONS.items()}
+        if not soft_constraints:
+            soft_constraints = None
+        if not static_params:
+            static_params = dict(self.DEFAULT_STATIC_PARAMS)
+        if not control_state:
+            control_state = []
+        self.control_state = control_state
+        self.soft_constraints = soft_constraints
+        env_properties = self.EnvProperties(
+            physical_normalizations=self.PhysicalState(**physical_normalizations),
+            action_normalizations=self.Action(**action_normalizations),
+            static_params=self.StaticParams(**static_params),
+        )
+        super().__init__(batch_size, env_properties=env_properties, tau=tau, solver=solver, dtype=dtype, device=device)
+
+
+class Pendulum(_SimpleEnv):
+    """State ``['theta', 'omega']``, action ``['torque']``; default reset theta=pi, omega=0
+    (pendulum_env.py:19-100)."""
+
+    ENV_ID = 0
+    STATE_FIELDS = ("theta", "omega")
+    ACTION_FIELDS = ("torque",)
+    PARAM_FIELDS = ("g", "l", "m")
+    DEFAULT_NORM_STATE = (1.0, 0.0)
+    PhysicalState = _dc("PhysicalState", STATE_FIELDS, "Physical state of the pendulum.")
+    Action = _dc("Action", ACTION_FIELDS, "Action of the pendulum.")
+    StaticParams = _dc("StaticParams", PARAM_FIELDS, "Static parameters of the pendulum.")
+    DEFAULT_PHYSICAL_NORMALIZATIONS = {"theta": (-math.pi, math.pi), "omega": (-10, 10)}
+    DEFAULT_ACTION_NORMALIZATIONS = {"torque": (-20, 20)}
+    DEFAULT_STATIC_PARAMS = {"g": 9.81, "l": 2, "m": 1}
+
+
+class MassSpringDamper(_SimpleEnv):
+    """State ``['deflection', 'velocity']``, action ``['force']`` (mass_spring_damper_env.py:50-98)."""
+
+    ENV_ID = 1
+    STATE_FIELDS = ("deflection", "velocity")
+    ACTION_FIELDS = ("force",)
+    PARAM_FIELDS = ("d", "k", "m")
+    DEFAULT_NORM_STATE = (0.0, 0.0)
+    PhysicalState = _dc("PhysicalState", STATE_FIELDS, "Physical state of the mass-spring-damper.")
+    Action = _dc("Action", ACTION_FIELDS, "Action of the mass-spring-damper.")
+    StaticParams = _dc("StaticParams", PARAM_FIELDS, "Static parameters of the mass-spring-damper.")
+    DEFAULT_PHYSICAL_NORMALIZATIONS = {"deflection": (-10, 10), "velocity": (-10, 10)}
+    DEFAULT_ACTION_NORMALIZATIONS = {"force": (-20, 20)}
+    DEFAULT_STATIC_PARAMS = {"k": 100, "d": 1, "m": 1}
+
+
+class CartPole(_SimpleEnv):
+    """State ``['deflection', 'velocity', 'theta', 'omega']``, action ``['force']``; default tau 2e-2
+    (cart_pole_env.py:50-110)."""
+
+    ENV_ID = 2
+    STATE_FIELDS = ("deflection", "velocity", "theta", "omega")
+    ACTION_FIELDS = ("force",)
+    PARAM_FIELDS = ("mu_p", "mu_c", "l", "m_p", "m_c", "g")
+    DEFAULT_NORM_STATE = (0.0, 0.0, 1.0, 0.0)
+    DEFAULT_TAU = 2e-2
+    PhysicalState = _dc("PhysicalState", STATE_FIELDS, "Physical state of the cart-pole.")
+    Action = _dc("Action", ACTION_FIELDS, "Action of the cart-pole.")
+    StaticParams = _dc("StaticParams", PARAM_FIELDS, "Static parameters of the cart-pole.")
+    DEFAULT_PHYSICAL_NORMALIZATIONS = {"deflection": (-2.4, 2.4), "velocity": (-8, 8), "theta": (-math.pi, math.pi),
+                                       "omega": (-8, 8)}
+    DEFAULT_ACTION_NORMALIZATIONS = {"force": (-20, 20)}
+    DEFAULT_STATIC_PARAMS = {"mu_p": 0.000002, "mu_c": 0.0005, "l": 0.5, "m_p": 0.1, "m_c": 1, "g": 9.81}
+
+
+class Acrobot(_SimpleEnv):
+    """State ``['theta_1', 'theta_2', 'omega_1', 'omega_2']``, action ``['torque']``; default tau 1e-3
+    (acrobot_env.py:50-133)."""
+
+    ENV_ID = 3
+    STATE_FIELDS = ("theta_1", "theta_2", "omega_1", "omega_2")
+    ACTION_FIELDS = ("torque",)
+    PARAM_FIELDS = ("g", "l_1", "l_2", "m_1", "m_2", "l_c1", "l_c2", "I_1", "I_2")
+    DEFAULT_NORM_STATE = (1.0, 0.0, 0.0, 0.0)
+    DEFAULT_TAU = 1e-3
+    PhysicalState = _dc("PhysicalState", STATE_FIELDS, "Physical state of the acrobot.")
+    Action = _dc("Action", ACTION_FIELDS, "Action of the acrobot.")
+    StaticParams = _dc("StaticParams", PARAM_FIELDS, "Static parameters of the acrobot.")
+    DEFAULT_PHYSICAL_NORMALIZATIONS = {"theta_1": (-math.pi, math.pi), "theta_2": (-math.pi, math.pi),
+                                       "omega_1": (-10, 10), "omega_2": (-10, 10)}
+    DEFAULT_ACTION_NORMALIZATIONS = {"torque": (-20, 20)}
+    DEFAULT_STATIC_PARAMS = {"g": 9.81, "l_1": 2, "l_2": 2, "m_1": 1, "m_2": 1, "l_c1": 1, "l_c2": 1, "I_1": 1.3,
+                             "I_2": 1.3}
+
+
+class FluidTank(_SimpleEnv):
+    """State ``['height']``, action ``['inflow']``; default batch 1, tau 1e-3, reset at normalised height 0.0
+    i.e. h = 1.5 m (fluid_tank_env.py:23-68,218-224)."""
+
+    ENV_ID = 4
+    STATE_FIELDS = ("height",)
+    ACTION_FIELDS = ("inflow",)
+    PARAM_FIELDS = ("base_area", "orifice_area", "c_d", "g")
+    DEFAULT_NORM_STATE = (0.0,)
+    DEFAULT_BATCH_SIZE = 1
+    DEFAULT_TAU = 1e-3
+    PhysicalState = _dc("PhysicalState", STATE_FIELDS, "Physical state of the fluid tank.")
+    Action = _dc("Action", ACTION_FIELDS, "Action of the fluid tank.")
+    StaticParams = _dc("StaticParams", PARAM_FIELDS, "Static parameters of the fluid tank.")
+    DEFAULT_PHYSICAL_NORMALIZATIONS = {"height": (0, 3)}
+    DEFAULT_ACTION_NORMALIZATIONS = {"inflow": (0, 0.2)}
+    DEFAULT_STATIC_PARAMS = {"base_area": math.pi, "orifice_area": math.pi * 0.1**2, "c_d": 0.6, "g": 9.81}
+
+    @property
+    def states_description(self):
+        return np.array(["fluid height"])
+
+    @property
+    def obs_description(self):
+        return np.hstack([self.states_description, np.array([n + "_ref" for n in self.control_state])])
+
+
+# ---------------------------------------------------------------------------------------------- PMSM
+class MotorVariant(Enum):
+    """pmsm/motor_parameters.py:152-163. The saturated (LUT) models of BRUSA / SEW are outside the hot path
+    (SURVEY.md §2); their linear parameter sets are provided."""
+
+    DEFAULT = "DEFAULT"
+    BRUSA = "BRUSA"
+    SEW = "SEW"
+
+    def get_params(self):
+        return _motor_params(self)
+
+
+@dataclass
+class MotorParams:
+    physical_normalizations: dict
+    action_normalizations: dict
+    static_params: dict
+
+
+def _motor_params(variant: MotorVariant) -> MotorParams:
+    """pmsm/motor_parameters.py:70-149."""
+    if variant is MotorVariant.SEW:
+        u, i_d, i_q, om, tq = 2 * 550 / 3, (-16, 0), (-16, 16), 4 * 2000 / 60 * 2 * math.pi, 15
+        sp = dict(p=4, r_s=208e-3, l_d=1.44e-3, l_q=1.44e-3, psi_p=122e-3, u_dc=550, deadtime=1)
+    else:
+        u, i_d, i_q, om, tq = 2 * 400 / 3, (-250, 0), (-250, 250), 3 * 11000 * 2 * math.pi / 60, 200
+        if variant is MotorVariant.BRUSA:
+            sp = dict(p=3, r_s=17.932e-3, l_d=0.37e-3, l_q=1.2e-3, psi_p=65.65e-3, u_dc=400, deadtime=1)
+        else:
+            sp = dict(p=3, r_s=15e-3, l_d=0.37e-3, l_q=1.2e-3, psi_p=65.6e-3, u_dc=400, deadtime=1)
+    pn = {
+        "u_d_buffer": MinMaxNormalization(-u, u), "u_q_buffer": MinMaxNormalization(-u, u),
+        "epsilon": MinMaxNormalization(-math.pi, math.pi), "i_d": MinMaxNormalization(*i_d),
+        "i_q": MinMaxNormalization(*i_q), "omega_el": MinMaxNormalization(0, om),
+        "torque": MinMaxNormalization(-tq, tq),
+    }
+    an = {"u_d": MinMaxNormalization(-u, u), "u_q": MinMaxNormalization(-u, u)}
+    return MotorParams(pn, an, sp)
+
+
+class PMSM(CoreEnvironment):
+    """Permanent-magnet synchronous motor, linear dq-frame model with voltage-hexagon clip and one-step action
+    dead time (pmsm/pmsm_env.py:115-267). ``saturated=True`` (LUT model) is out of the hot-path scope."""
+
+    ENV_ID = 5
+    STATE_FIELDS = ("u_d_buffer", "u_q_buffer", "epsilon", "i_d", "i_q", "torque", "omega_el")
+    ACTION_FIELDS = ("u_d", "u_q")
+    PARAM_FIELDS = ("p", "r_s", "l_d", "l_q", "psi_p", "u_dc", "deadtime")
+    PhysicalState = _dc("PhysicalState", STATE_FIELDS, "Physical state of the PMSM.")
+    Action = _dc("Action", ACTION_FIELDS, "Action of the PMSM.")
+    StaticParams = _dc("StaticParams", PARAM_FIELDS, "Static parameters of the PMSM.")
+    Additions = _Additions
+
+    @dataclass
+    class EnvProperties:
+        """pmsm_env.py:307-314."""
+
+        saturated: Any
+        physical_normalizations: Any
+        action_normalizations: Any
+        static_params: Any
+
+    def __init__(self, batch_size: int = 8, saturated=False, motor_variant: MotorVariant = MotorVariant.DEFAULT,
+                 physical_normalizations: dict = None, action_normalizations: dict = None,
+                 soft_constraints: Callable = None, static_params: dict = None, control_state: list = None,
+                 solver=Euler(), tau: float = 1e-4, dtype=torch.float32, device=None):
+        if saturated:
+            if motor_variant == MotorVariant.DEFAULT:
+                raise ValueError(
+                    f"MotorVariant '{motor_variant.value}' is not allowed for saturated LUTs. "
+                    "Use a specific motor variant. DEFAULT is only valid for saturated=False."
+                )
+            raise NotImplementedError("PMSM(saturated=True): the LUT model is outside the accelerated hot path "
+                                      "(SURVEY.md §2, §8f rank 3)")
+        motor_params = motor_variant.get_params()
+        if not static_params:
+            static_params = motor_params.static_params
+        if not physical_normalizations:
+            physical_normalizations = motor_params.physical_normalizations
+        if not action_normalizations:
+            action_normalizations = motor_params.action_normalizations
+        if not control_state:
+            control_state = []
+        self.control_state = control_state
+        self.soft_constraints = soft_constraints
+        env_properties = self.EnvProperties(
+            saturated=saturated,
+            physical_normalizations=self.PhysicalState(**physical_normalizations),
+            action_normalizations=self.Action(**action_normalizations),
+            static_params=self.StaticParams(**static_params),
+        )
+        super().__init__(batch_size, env_properties=env_properties, tau=tau, solver=solver, dtype=dtype, device=device)
+        self._action_description = ["u_d", "u_q"]
+        self._obs_description = ["i_d", "i_q", "cos_eps", "sin_eps", "omega_el", "torque", "u_d_buffer", "u_q_buffer"]
+
+    def create_in_axes_dataclass(self, dataclass_obj):
+        if isinstance(dataclass_obj, PMSM.EnvProperties):  # `saturated` is a plain bool leaf
+            sub = super().create_in_axes_dataclass(replace(dataclass_obj, saturated=0.0))
+            return replace(sub, saturated=None)
+        return super().create_in_axes_dataclass(dataclass_obj)
+
+    def _init_state(self, env_properties, rng, shape):
+        """pmsm_env.py:383-485: physical units directly (no denormalisation pass)."""
+        pn = env_properties.physical_normalizations
+        full = lambda v: torch.as_tensor(v, dtype=self.dtype, device=self.device).expand(shape).clone()
+        lo_hi = lambda n: (self._norm_leaf(getattr(pn, n).min), self._norm_leaf(getattr(pn, n).max))
+        if rng is None:
+            i_lo, i_hi = lo_hi("i_d")
+            o_lo, o_hi = lo_hi("omega_el")
+            phys = dict(u_d_buffer=full(0.0), u_q_buffer=full(0.0), epsilon=full(0.0), i_d=full((i_lo + i_hi) / 2),
+                        i_q=full(0.0), torque=full(0.0), omega_el=full((o_lo + o_hi) / 2))
+        else:
+            gen = rng
+            if not isinstance(rng, torch.Generator):
+                gen = torch.Generator(device=self.device)
+                gen.manual_seed(int(rng))
+            u = lambda: torch.rand(shape, generator=gen, dtype=self.dtype, device=self.device)
+            state_norm = [u() * 2 - 1, u() * 2 - 1]
+            r, phi = torch.sqrt(u()), u() * (2 * math.pi)  # uniform in the unit disc (jax.random.ball(key, 2))
+            (d_lo, d_hi), (q_lo, q_hi) = lo_hi("i_d"), lo_hi("i_q")
+            i_max = torch.as_tensor(max(abs(float(torch.as_tensor(v).max())) for v in (d_lo, d_hi, q_lo, q_hi)))
+            i_d, i_q = r * torch.cos(phi) * i_max, r * torch.sin(phi) * i_max
+            relu = torch.nn.functional.relu
+            i_d = i_d - 2 * relu(i_d - d_hi) + 2 * relu(-i_d + d_lo)
+            i_q = i_q - 2 * relu(i_q - q_hi) + 2 * relu(-i_q + q_lo)
+            sp = env_properties.static_params
+            leaf = self._norm_leaf
+            torque = 1.5 * leaf(sp.p) * (leaf(sp.psi_p) + (leaf(sp.l_d) - leaf(sp.l_q)) * i_d) * i_q
+            (e_lo, e_hi), (o_lo, o_hi) = lo_hi("epsilon"), lo_hi("omega_el")
+            phys = dict(u_d_buffer=full(0.0), u_q_buffer=full(0.0),
+                        epsilon=(state_norm[0] + 1) / 2 * (e_hi - e_lo) + e_lo, i_d=i_d, i_q=i_q, torque=torque,
+                        omega_el=(state_norm[1] + 1) / 2 * (o_hi - o_lo) + o_lo)
+        ref = {n: self._nan(shape) for n in self.STATE_FIELDS}
+        return self.State(physical_state=self.PhysicalState(**phys), PRNGKey=self._nan(shape),
+                          additions=self._additions(shape, False), reference=self.PhysicalState(**ref))
+
+    def generate_observation(self, system_state, env_properties):
+        """pmsm_env.py:898-919: [i_d, i_q, omega_el, torque, cos(eps), sin(eps), u_d_buffer, u_q_buffer] (+ refs)."""
+        eps = system_state.physical_state.epsilon
+        ns = self.normalize_state(system_state, env_properties)
+        p = ns.physical_state
+        cols = [p.i_d, p.i_q, p.omega_el, p.torque, torch.cos(eps), torch.sin(eps), p.u_d_buffer, p.u_q_buffer]
+        cols += [getattr(ns.reference, n) for n in self.control_state]
+        return torch.stack(torch.broadcast_tensors(*cols), dim=-1)
+
+    def generate_state_from_observation(self, obs, env_properties, key=None):
+        """pmsm_env.py:921-970."""
+        obs = self._t(obs)
+        shape = tuple(obs.shape[:-1])
+        phys = dict(u_d_buffer=obs[..., 6], u_q_buffer=obs[..., 7],
+                    epsilon=torch.atan2(obs[..., 5], obs[..., 4]) / math.pi, i_d=obs[..., 0], i_q=obs[..., 1],
+                    torque=obs[..., 3], omega_el=obs[..., 2])
+        ref = {n: self._nan(shape) for n in self.STATE_FIELDS}
+        for pos, n in enumerate(self.control_state):
+            ref[n] = obs[..., 8 + pos]
+        norm_state = self.State(physical_state=self.PhysicalState(**phys),
+                                PRNGKey=self._nan(shape) if key is None else key,
+                                additions=self._additions(shape, False), reference=self.PhysicalState(**ref))
+        return self.denormalize_state(norm_state, env_properties)
+
+    @property
+    def action_description(self):
+        return self._action_description
+
+    @property
+    def obs_description(self):
+        return np.hstack([np.array(self._obs_description), np.array([n + "_ref" for n in self.control_state])])

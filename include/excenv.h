@@ -135,6 +135,11 @@ int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
                      void* obs_traj, void* const* state_traj, int traj_layout,
                      void* const* last_state, int semantics, void* stream);
 
+/* ---- tuning (no reference counterpart) -------------------------------------------------------
+ * key 0: environments per lane for lane-major trajectories (0 = auto, 1/2/4 = forced). Process-wide.
+ * Returns the previous value, or EXCENV_EINVAL for an unknown key. */
+int excenv_set_tuning(int key, int value);
+
 /* ---- device-math probes (tests only): out[i] = f(in[i]) for the in-kernel fp32 routines -- */
 int excenv_probe_math(int which /*0 sin,1 cos,2 wrap_angle*/, int dtype, int64_t n,
                       const void* in, void* out, void* stream);

@@ -1,0 +1,326 @@
+"""Parity of the HIP kernels (through the Python mirror -> C ABI) against the reference's golden fixtures and
+the fixture-pinned CPU oracle. Everything here needs an MI355X: run with ``-m gpu``.
+
+Tolerances (stated per regime, SURVEY.md §7 "Tolerance must be stated per regime"):
+  * fp64 kernel vs the reference fixtures: the reference's own ``allclose(rtol=1e-16 | 1e-8, atol=1e-8)``.
+  * trig-free environments (mass-spring-damper, fluid tank), any dtype, any solver: BIT-EXACT vs the oracle.
+  * environments with sin/cos: fp64 <= 1e-9, fp32 <= 1e-5 relative (+ the same absolute floor on O(1) normalised
+    observations), short horizons so chaotic amplification does not mask a real bug.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import ENV_NAMES, golden_rtol
+from helpers import (ANGLE_OBS, ANGLE_STATES, NP_DTYPE, TRIG_FREE, circ_close, make_env, max_err, phys_np,
+                     random_state, spec_of, to_state)
+
+pytestmark = pytest.mark.gpu
+
+SOLVERS = ["euler", "rk4", "tsit5"]
+
+
+def _tol(env, dtype):
+    if env in TRIG_FREE:
+        return 0.0, 0.0
+    return (1e-9, 1e-9) if dtype == torch.float64 else (1e-5, 1e-5)
+
+
+def _close(env, got, want, dtype, obs_cols=True):
+    rtol, atol = _tol(env, dtype)
+    if rtol == 0.0:
+        return np.array_equal(np.asarray(got), np.asarray(want), equal_nan=True)
+    cols = ANGLE_OBS.get(env, []) if obs_cols else []
+    return circ_close(got, want, cols, rtol, atol)
+
+
+# ------------------------------------------------------------------------------------------------ fixtures
+@pytest.mark.parametrize("env_name", ENV_NAMES)
+def test_fixture_step_path_fp64(env_name, golden):
+    """The reference's test_step_results on the GPU: K launches of vmap_step, fp64, Euler, B replicas."""
+    g = golden[env_name]
+    B = 64
+    env, props, keep, spec = make_env(env_name, B, torch.float64)
+    obs0 = torch.as_tensor(np.repeat(g["observations"][:1], B, axis=0), device=env.device)
+    state = env.vmap_generate_state_from_observation(obs0)
+    acts = torch.as_tensor(g["actions"], dtype=torch.float64, device=env.device)
+    gen = [obs0]
+    for k in range(acts.shape[0]):
+        obs, state = env.vmap_step(state, acts[k].expand(B, -1))
+        gen.append(obs)
+    gen = torch.stack(gen, dim=1).cpu().numpy()
+    for b in (0, B - 1):
+        assert np.allclose(gen[b], g["observations"], rtol=golden_rtol(env_name), atol=1e-8)
+    assert np.array_equal(gen, np.repeat(gen[:1], B, axis=0))
+
+
+@pytest.mark.parametrize("layout", ["lane_major", "env_major"])
+@pytest.mark.parametrize("env_name", ENV_NAMES)
+def test_fixture_sim_ahead_fp64(env_name, layout, golden):
+    """One persistent launch over the whole fixture (10 000 steps; PMSM 1 000), SEM_STEP: reproduces the fixture
+    and is bit-identical to K vmap_step launches."""
+    g = golden[env_name]
+    B = 8
+    env, props, keep, spec = make_env(env_name, B, torch.float64)
+    env.sim_ahead_semantics = "step"
+    env.traj_layout = layout
+    obs0 = torch.as_tensor(np.repeat(g["observations"][:1], B, axis=0), device=env.device)
+    state = env.vmap_generate_state_from_observation(obs0)
+    acts = torch.as_tensor(np.repeat(g["actions"][None], B, axis=0), device=env.device)
+    obs, states, last = env.vmap_sim_ahead(state, acts, env.tau, env.tau)
+    got = obs.cpu().numpy()
+    assert got.shape == (B,) + g["observations"].shape
+    assert np.allclose(got[0][1:], g["observations"][1:], rtol=golden_rtol(env_name), atol=1e-8)
+    assert np.array_equal(got, np.repeat(got[:1], B, axis=0))
+    s = state
+    for k in range(200):
+        o, s = env.vmap_step(s, acts[:, k])
+        assert torch.equal(o, obs[:, k + 1]), f"step {k}"
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(last.physical_state, n), getattr(states.physical_state, n)[:, -1])
+
+
+# ------------------------------------------------------------------------------------------------ vs oracle
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("solver", SOLVERS)
+@pytest.mark.parametrize("env_name", ENV_NAMES)
+def test_vmap_step_matches_oracle(env_name, solver, dtype):
+    B = 4096 + 37  # ragged: not a multiple of the workgroup size
+    env, props, keep, spec = make_env(env_name, B, dtype, solver)
+    st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=11)
+    rng = np.random.default_rng(12)
+    act = rng.uniform(-1.2, 1.2, (B, env.action_dim)).astype(NP_DTYPE[dtype])
+    obs, new = env.vmap_step(to_state(env, st), torch.as_tensor(act, device=env.device))
+    o_ref, s_ref = oracle.step(env_name, solver, st, act, props, spec["tau"])
+    assert obs.shape == o_ref.shape
+    assert _close(env_name, obs.cpu().numpy(), o_ref, dtype), max_err(obs.cpu().numpy(), o_ref)
+    got = phys_np(env, new)
+    rtol, atol = _tol(env_name, dtype)
+    for j, n in enumerate(env.STATE_FIELDS):
+        scale = max(1.0, float(np.abs(s_ref[j]).max()))
+        if rtol == 0:
+            assert np.array_equal(got[j], s_ref[j]), n
+        elif j in ANGLE_STATES.get(env_name, []):
+            assert circ_close(got[j][:, None], s_ref[j][:, None], [0], rtol, atol * scale, period=2 * np.pi), n
+        else:
+            assert np.allclose(got[j], s_ref[j], rtol=rtol, atol=atol * scale), (n, max_err(got[j], s_ref[j]))
+    assert bool(new.additions.active_solver_state.all())
+
+
+@pytest.mark.parametrize("semantics", ["step", "ahead"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("solver", SOLVERS)
+@pytest.mark.parametrize("env_name", ENV_NAMES)
+def test_vmap_sim_ahead_matches_oracle(env_name, solver, dtype, semantics):
+    """Lane-major fast path (V envs per lane) on a batch divisible by 4, K = 64."""
+    B, K = 2048, 64
+    env, props, keep, spec = make_env(env_name, B, dtype, solver)
+    env.sim_ahead_semantics = semantics
+    st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=21)
+    rng = np.random.default_rng(22)
+    acts = rng.uniform(-1, 1, (B, K, env.action_dim)).astype(NP_DTYPE[dtype])
+    a_dev = env.new_actions_buffer(K)
+    a_dev.copy_(torch.as_tensor(acts, device=env.device))
+    obs, states, last = env.vmap_sim_ahead(to_state(env, st), a_dev, env.tau, env.tau)
+    sem = oracle.SEM_STEP if semantics == "step" else oracle.SEM_AHEAD
+    o_ref, s_ref, l_ref = oracle.sim_ahead(env_name, solver, st, acts, props, spec["tau"], semantics=sem)
+    assert tuple(obs.shape) == o_ref.shape
+    assert _close(env_name, obs.cpu().numpy(), o_ref, dtype), max_err(obs.cpu().numpy(), o_ref)
+    rtol, atol = _tol(env_name, dtype)
+    for j, n in enumerate(env.STATE_FIELDS):
+        got = getattr(states.physical_state, n).cpu().numpy()
+        got_last = getattr(last.physical_state, n).cpu().numpy()
+        assert np.array_equal(got[:, -1], got_last)
+        scale = max(1.0, float(np.nanmax(np.abs(s_ref[j]))))
+        if rtol == 0:
+            assert np.array_equal(got, s_ref[j]), n
+        elif j in ANGLE_STATES.get(env_name, []):
+            assert circ_close(got[..., None], s_ref[j][..., None], [0], rtol, atol * scale, period=2 * np.pi), n
+        else:
+            assert np.allclose(got, s_ref[j], rtol=rtol, atol=atol * scale), (n, max_err(got, s_ref[j]))
+
+
+@pytest.mark.parametrize("vec", [1, 2, 4])
+@pytest.mark.parametrize("env_name", ["pmsm", "pendulum", "mass_spring_damper"])
+def test_envs_per_lane_variants_are_bit_identical(env_name, vec):
+    """V = 1 / 2 / 4 environments per lane and the env-major (reference row-major) layout give identical bits."""
+    from exciting_environments_amd import _native
+
+    B, K = 1024, 33
+    env, props, keep, spec = make_env(env_name, B, torch.float32)
+    st = random_state(env_name, B, np.float32, spec, seed=31)
+    acts = np.random.default_rng(32).uniform(-1, 1, (B, K, env.action_dim)).astype(np.float32)
+    a_lane = env.new_actions_buffer(K)
+    a_lane.copy_(torch.as_tensor(acts, device=env.device))
+    a_env = torch.as_tensor(acts, device=env.device)
+    env.traj_layout = "env_major"
+    ref_obs, ref_states, ref_last = env.vmap_sim_ahead(to_state(env, st), a_env, env.tau, env.tau)
+    assert ref_obs.is_contiguous()
+    env.traj_layout = "lane_major"
+    old = _native.set_tuning(0, vec)
+    try:
+        obs, states, last = env.vmap_sim_ahead(to_state(env, st), a_lane, env.tau, env.tau)
+    finally:
+        _native.set_tuning(0, old)
+    assert torch.equal(obs, ref_obs)
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(states.physical_state, n), getattr(ref_states.physical_state, n))
+        assert torch.equal(getattr(last.physical_state, n), getattr(ref_last.physical_state, n))
+
+
+@pytest.mark.parametrize("env_name", ["pendulum", "pmsm", "cartpole"])
+def test_per_env_property_arrays(env_name):
+    """Static params / normalisation bounds given as [batch_size] arrays (reference test_custom_initialization,
+    e.g. tests/envs/pendulum/test_pendulum.py:72-129)."""
+    B, K = 777, 20
+    dtype = torch.float64
+    spec = spec_of(env_name)
+    rng = np.random.default_rng(41)
+    if env_name == "pendulum":
+        spec["params"]["l"] = rng.uniform(0.5, 2.5, B)
+        spec["phys_norm"]["omega"] = (rng.uniform(-12, -8, B), 10)
+        spec["act_norm"]["torque"] = (-20, rng.uniform(15, 25, B))
+    elif env_name == "pmsm":
+        spec["params"]["r_s"] = rng.uniform(10e-3, 20e-3, B)
+        spec["params"]["p"] = np.full(B, 3.0)
+        spec["phys_norm"]["i_q"] = (-250, rng.uniform(200, 300, B))
+    else:
+        spec["params"]["m_p"] = rng.uniform(0.05, 0.2, B)
+        spec["params"]["mu_c"] = rng.uniform(0.0, 0.001, B)
+    env, props, keep, _ = make_env(env_name, B, dtype, spec=spec)
+    env.sim_ahead_semantics = "step"
+    st = random_state(env_name, B, np.float64, spec, seed=42)
+    acts = rng.uniform(-1, 1, (B, K, env.action_dim))
+    obs, states, last = env.vmap_sim_ahead(to_state(env, st), torch.as_tensor(acts, device=env.device), env.tau, env.tau)
+    o_ref, _, _ = oracle.sim_ahead(env_name, "euler", st, acts, props, spec["tau"])
+    assert _close(env_name, obs.cpu().numpy(), o_ref, dtype), max_err(obs.cpu().numpy(), o_ref)
+    o1, _ = env.vmap_step(to_state(env, st), torch.as_tensor(acts[:, 0], device=env.device))
+    r1, _ = oracle.step(env_name, "euler", st, acts[:, 0], props, spec["tau"])
+    assert _close(env_name, o1.cpu().numpy(), r1, dtype)
+
+
+def test_control_state_reference_columns():
+    """generate_observation appends the normalised reference of every control_state name (pendulum_env.py:322-328)."""
+    B, K = 512, 9
+    env, props, keep, spec = make_env("cartpole", B, torch.float32, control_state=["theta", "deflection"])
+    st = random_state("cartpole", B, np.float32, spec, seed=51)
+    rng = np.random.default_rng(52)
+    refs = {"theta": rng.uniform(-3, 3, B).astype(np.float32), "deflection": rng.uniform(-2, 2, B).astype(np.float32)}
+    acts = rng.uniform(-1, 1, (B, K, 1)).astype(np.float32)
+    state = to_state(env, st, reference=refs)
+    control = [("theta", refs["theta"]), ("deflection", refs["deflection"])]
+    assert len(env.obs_description) == 6
+    obs, _ = env.vmap_step(state, torch.as_tensor(acts[:, 0], device=env.device))
+    o_ref, _ = oracle.step("cartpole", "euler", st, acts[:, 0], props, spec["tau"], control=control)
+    assert obs.shape == (B, 6) and _close("cartpole", obs.cpu().numpy(), o_ref, torch.float32)
+    for layout in ("lane_major", "env_major"):
+        env.traj_layout = layout
+        obs, states, last = env.vmap_sim_ahead(state, torch.as_tensor(acts, device=env.device), env.tau, env.tau)
+        o_ref, _, _ = oracle.sim_ahead("cartpole", "euler", st, acts, props, spec["tau"], semantics=oracle.SEM_AHEAD,
+                                       control=control)
+        assert obs.shape == (B, K + 1, 6) and _close("cartpole", obs.cpu().numpy(), o_ref, torch.float32)
+        assert torch.equal(states.reference.theta[:, 3], state.reference.theta)
+
+
+@pytest.mark.parametrize("env_name", ["pendulum", "fluid_tank", "acrobot"])
+def test_substeps_obs_stepsize_smaller_than_action_stepsize(env_name):
+    """obs_stepsize < action_stepsize: each action is held for `substeps` solver steps, N+1 = K*substeps+1 rows."""
+    B, K, sub = 256, 7, 4
+    env, props, keep, spec = make_env(env_name, B, torch.float64, "rk4")
+    st = random_state(env_name, B, np.float64, spec, seed=61)
+    acts = np.random.default_rng(62).uniform(-1, 1, (B, K, 1))
+    obs, states, last = env.vmap_sim_ahead(to_state(env, st), torch.as_tensor(acts, device=env.device),
+                                           env.tau / sub, env.tau)
+    o_ref, _, _ = oracle.sim_ahead(env_name, "rk4", st, acts, props, spec["tau"] / sub, env_tau=spec["tau"],
+                                   substeps=sub, semantics=oracle.SEM_AHEAD)
+    assert obs.shape == (B, K * sub + 1, env.physical_state_dim)
+    assert _close(env_name, obs.cpu().numpy(), o_ref, torch.float64), max_err(obs.cpu().numpy(), o_ref)
+
+
+def test_fluid_tank_empties_step_vs_ahead_semantics():
+    """fluid_tank_env.py:146 vs :196 — `step` clips h >= 0 after every step, sim_ahead only clips the saved rows."""
+    B, K = 64, 400
+    spec = spec_of("fluid_tank")
+    spec["tau"] = 5e-2
+    spec["act_norm"]["inflow"] = (-0.2, 0.2)  # allows draining below zero
+    for sem, osem in (("step", oracle.SEM_STEP), ("ahead", oracle.SEM_AHEAD)):
+        env, props, keep, _ = make_env("fluid_tank", B, torch.float32, spec=spec)
+        env.sim_ahead_semantics = sem
+        st = [np.linspace(0.001, 0.05, B).astype(np.float32)]
+        acts = np.random.default_rng(71).uniform(-1, 0.2, (B, K, 1)).astype(np.float32)
+        obs, states, last = env.vmap_sim_ahead(to_state(env, st), torch.as_tensor(acts, device=env.device), env.tau, env.tau)
+        o_ref, s_ref, _ = oracle.sim_ahead("fluid_tank", "euler", st, acts, props, spec["tau"], semantics=osem)
+        assert np.array_equal(obs.cpu().numpy(), o_ref)
+        assert float(states.physical_state.height.min()) == 0.0  # the tank did empty
+
+
+def test_pmsm_deadtime_zero_and_nan_propagation():
+    B, K = 256, 12
+    spec = spec_of("pmsm")
+    spec["params"]["deadtime"] = 0
+    for sem, osem in (("step", oracle.SEM_STEP), ("ahead", oracle.SEM_AHEAD)):
+        env, props, keep, _ = make_env("pmsm", B, torch.float32, spec=spec)
+        env.sim_ahead_semantics = sem
+        st = random_state("pmsm", B, np.float32, spec, seed=81)
+        acts = np.random.default_rng(82).uniform(-1, 1, (B, K, 2)).astype(np.float32)
+        acts[3, 5, 0] = np.nan  # runtime numeric problems surface as NaN, never as exceptions
+        obs, _, _ = env.vmap_sim_ahead(to_state(env, st), torch.as_tensor(acts, device=env.device), env.tau, env.tau)
+        o_ref, _, _ = oracle.sim_ahead("pmsm", "euler", st, acts, props, spec["tau"], semantics=osem)
+        got = obs.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(o_ref))
+        assert np.allclose(got, o_ref, rtol=1e-5, atol=1e-5, equal_nan=True)
+
+
+def test_single_env_api_and_empty_trajectory():
+    """step / sim_ahead for one environment (core_env.py:393-488) and K = 0."""
+    env, props1, keep, spec = make_env("pendulum", 1, torch.float64)
+    obs, state = env.reset(env.env_properties)
+    assert obs.shape == (2,)
+    o, s = env.step(state, torch.ones(1), env.env_properties)
+    r, _ = oracle.step("pendulum", "euler", [np.array([np.pi]), np.array([0.0])], np.ones((1, 1)), props1, spec["tau"])
+    assert np.allclose(o.cpu().numpy(), r[0], rtol=1e-12, atol=1e-12)
+    acts = torch.ones((10, 1), dtype=torch.float64)
+    obs_t, states, last = env.sim_ahead(state, acts, env.env_properties, env.tau, env.tau)
+    assert obs_t.shape == (11, 2) and states.physical_state.theta.shape == (11,)
+    from exciting_environments_amd.tree import tree_structure
+    assert tree_structure(last) == tree_structure(state)
+    env4, _, _, _ = make_env("pendulum", 4, torch.float32)
+    _, st4 = env4.vmap_reset()
+    o0, s0, l0 = env4.vmap_sim_ahead(st4, torch.empty((4, 0, 1)), env4.tau, env4.tau)
+    assert o0.shape == (4, 1, 2)
+    assert torch.equal(l0.physical_state.omega, st4.physical_state.omega)
+
+
+# ------------------------------------------------------------------------------------------------ device math
+def test_device_sincos_fp32_within_2ulp():
+    from exciting_environments_amd import _native
+
+    x = torch.cat([torch.linspace(-3.1415927, 3.1415927, 2_000_001), torch.linspace(-50, 50, 500_001),
+                   torch.tensor([0.0, -0.0, 1e-30, -1e-20, 3.1415927, -3.1415927, 1.5707964, 1000.0, 1e6, 1e10])]
+                  ).to(torch.float32).cuda()
+    for which, fn in ((0, np.sin), (1, np.cos)):
+        got = _native.probe_math(which, x).cpu().numpy().astype(np.float64)
+        want = fn(x.cpu().numpy().astype(np.float64))
+        ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+        err = np.abs(got - want) / np.maximum(ulp, 2.0**-149)
+        # near the zeros of sin/cos the reduction's absolute error (~1e-9) dominates the shrinking ulp
+        ok = (err <= 2.0) | (np.abs(got - want) <= 4e-9)
+        assert ok.all(), (which, float(err[~ok].max()))
+
+
+def test_device_wrap_angle_is_python_modulo_bit_exact():
+    from exciting_environments_amd import _native
+
+    rng = np.random.default_rng(5)
+    for dt, npdt in ((torch.float32, np.float32), (torch.float64, np.float64)):
+        pi, two_pi = npdt(np.pi), npdt(2 * np.pi)
+        x = np.concatenate([rng.uniform(-10, 10, 1_000_000), rng.uniform(-1e4, 1e4, 200_000),
+                            rng.uniform(-1e9, 1e9, 1000), np.arange(-8, 9) * np.pi, np.arange(-8, 9) * 2 * np.pi,
+                            [0.0, -0.0, np.pi, -np.pi, 3 * np.pi, 1e-40, -1e-40]]).astype(npdt)
+        want = np.remainder(x + pi, two_pi) - pi
+        got = _native.probe_math(2, torch.as_tensor(x).cuda()).cpu().numpy()
+        assert got.dtype == want.dtype
+        assert np.array_equal(got, want), (dt, int((got != want).sum()))
+        for bad in (np.nan, np.inf, -np.inf):
+            assert np.isnan(_native.probe_math(2, torch.tensor([bad], dtype=dt).cuda()).item())
