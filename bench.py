@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s and achieved HBM GB/s of the persistent vmap_sim_ahead kernel.
+
+Workload (BASELINE.json configs[2]): PMSM dq-frame, explicit Euler, fp32, batch 2^22 per GPU,
+tau = 1e-4. One bench "step" = one vmap_sim_ahead launch of `--chunk` (default 100) solver steps over the whole
+batch with full reference outputs (observations + all physical-state trajectories); chunks are chained through
+last_state, so the default 100 timed steps are the 10 000-step run. Inputs (initial state, one action chunk that
+every step reuses) are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: launched by torch.distributed.run, one rank per GPU, batch sharded (weak scaling: 2^22 envs per rank),
+no collective on the stepping path; the final observation row of every chunk is all-gathered (RCCL) on a side
+stream, overlapped with the next chunk (`--gather none` disables it).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "exciting-environments_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+WORKLOADS = {
+    # name: (registry, solver, dtype, tau, log2 batch, default chunk)
+    "pmsm_euler_f32": ("PMSM", "euler", torch.float32, 1e-4, 22, 100),
+    "pendulum_euler_f32": ("PENDULUM", "euler", torch.float32, 2e-2, 20, 1000),
+    "msd_tsit5_f64": ("MASS_SPRING_DAMPER", "tsit5", torch.float64, 1e-4, 20, 500),
+}
+ORACLE_NAME = {"PMSM": "pmsm", "PENDULUM": "pendulum", "MASS_SPRING_DAMPER": "mass_spring_damper"}
+
+
+def build_env(args, device, rank):
+    import exciting_environments_amd as ex
+    from exciting_environments_amd import EnvironmentRegistry
+
+    reg, solver, dtype, tau, log2b, chunk = WORKLOADS[args.workload]
+    B = args.batch or (1 << log2b)
+    Kc = args.chunk or chunk
+    solv = {"euler": ex.Euler(), "rk4": ex.RK4(), "tsit5": ex.Tsit5()}[solver]
+    env = getattr(EnvironmentRegistry, reg).make(batch_size=B, tau=tau, solver=solv, dtype=dtype, device=device)
+    env.sim_ahead_semantics = args.semantics
+    _, state = env.vmap_reset()
+    g = torch.Generator(device=device)
+    g.manual_seed(1236 + rank)
+    u = lambda lo, hi: torch.rand(B, generator=g, dtype=dtype, device=device) * (hi - lo) + lo
+    ps = state.physical_state
+    if reg == "PMSM":  # stable region omega_el <= 600 rad/s
+        ps.i_d = torch.full((B,), -125.0, dtype=dtype, device=device)
+        ps.epsilon = u(-np.pi, np.pi)
+        ps.omega_el = u(0.0, 600.0)
+    elif reg == "PENDULUM":
+        ps.theta, ps.omega = u(-np.pi, np.pi), u(-1.0, 1.0)
+    g.manual_seed(1237 + rank)
+    actions = env.new_actions_buffer(Kc) if args.action_layout == "lane_major" else torch.empty(
+        (B, Kc, env.action_dim), dtype=dtype, device=device)
+    flat = torch.rand(actions.numel(), generator=g, dtype=dtype, device=device) * 2 - 1
+    actions.copy_(flat.view(Kc, env.action_dim, B).permute(2, 0, 1))
+    del flat
+    env.traj_layout = args.traj_layout
+    return env, state, actions, B, Kc, reg, solver, dtype
+
+
+def cpu_baseline(args, reg, solver, dtype, tau, Kc):
+    """The CPU oracle (C/OpenMP restatement pinned to the reference fixtures) timed on this host's cores on a
+    bounded sample of the same workload. Reported beside the GPU number; it is a baseline, not the target."""
+    import oracle
+
+    name = ORACLE_NAME[reg]
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    Bc = 1 << 16
+    from exciting_environments_amd import EnvironmentRegistry
+
+    env = getattr(EnvironmentRegistry, reg).make(batch_size=Bc, tau=tau, dtype=dtype, device="cpu")
+    ep = env.env_properties
+    params = {n: getattr(ep.static_params, n) for n in env.PARAM_FIELDS}
+    pn = {n: (getattr(ep.physical_normalizations, n).min, getattr(ep.physical_normalizations, n).max) for n in env.STATE_FIELDS}
+    an = {n: (getattr(ep.action_normalizations, n).min, getattr(ep.action_normalizations, n).max) for n in env.ACTION_FIELDS}
+    props, keep = oracle.make_props(name, params, pn, an, npdt, Bc)
+    rng = np.random.default_rng(1236)
+    _, st = env.vmap_reset()
+    st_np = [getattr(st.physical_state, n).numpy().astype(npdt) for n in env.STATE_FIELDS]
+    if name == "pmsm":
+        st_np[2] = rng.uniform(-np.pi, np.pi, Bc).astype(npdt)
+        st_np[6] = rng.uniform(0, 600, Bc).astype(npdt)
+    acts = rng.uniform(-1, 1, (Bc, Kc, env.action_dim)).astype(npdt)
+    sem = oracle.SEM_AHEAD if args.semantics == "ahead" else oracle.SEM_STEP
+    oracle.sim_ahead(name, solver, st_np, acts, props, tau, semantics=sem)  # warm-up (thread pool, page faults)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        _, _, last = oracle.sim_ahead(name, solver, st_np, acts, props, tau, semantics=sem)
+        st_np = last
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or reps >= 10000:
+            break
+    return {
+        "value": Bc * Kc * reps / el, "unit": "env-steps/s", "cores": oracle.num_threads(), "kind": "port",
+        "sample": f"oracle/liboracle.so (C+OpenMP restatement, env-major layout) {name} {solver} "
+                  f"{np.dtype(npdt).name} B=2^16 x {Kc} steps x {reps} chained chunks, {el:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pmsm_euler_f32", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="envs per GPU (default: the workload's 2^n)")
+    ap.add_argument("--chunk", type=int, default=0, help="solver steps per launch")
+    ap.add_argument("--semantics", default="ahead", choices=["ahead", "step"])
+    ap.add_argument("--traj-layout", default="lane_major", choices=["lane_major", "env_major"])
+    ap.add_argument("--action-layout", default="lane_major", choices=["lane_major", "env_major"])
+    ap.add_argument("--gather", default="final", choices=["final", "none"])
+    ap.add_argument("--vec", type=int, default=0, help="envs per lane (0 auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from exciting_environments_amd import _native
+    from exciting_environments_amd.distributed import ObservationGatherer
+
+    env, state, actions, B, Kc, reg, solver, dtype = build_env(args, device, rank)
+    if args.vec:
+        _native.set_tuning(0, args.vec)
+    gatherer = ObservationGatherer(B * world) if (world > 1 and args.gather == "final") else None
+    gathered = None
+
+    def one_step(st):
+        nonlocal gathered
+        obs, states, last = env.vmap_sim_ahead(st, actions, env.tau, env.tau)
+        if gatherer is not None:
+            gatherer.wait()  # previous chunk's gather must have drained before its buffer is reused
+            gathered = gatherer.start(obs[:, -1, :], gathered)
+        return last
+
+    for _ in range(args.warmup):
+        state = one_step(state)
+    if gatherer is not None:
+        gatherer.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        state = one_step(state)
+        ev[k][1].record()
+    if gatherer is not None:
+        gatherer.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    finite = bool(torch.isfinite(state.physical_state.__dict__[env.STATE_FIELDS[-1]]).all())
+    # events bracket the launch on the launch stream; with the gather enabled the bracket also holds the
+    # (asynchronous) enqueue of the collective but no wait for it
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    bytes_per_step = _native.sim_ahead_bytes(env.ENV_ID, dtype, True)
+    algo_bytes = bytes_per_step * B * Kc
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if args.steps else float("nan")
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"{args.workload}|B={B}|chunk={Kc}|{args.traj_layout}"
+            if key in tj:
+                traffic = tj[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        total_steps = B * world * Kc * args.steps
+        out = {
+            "metric": "env-steps/sec + achieved HBM GB/s, PMSM Euler fp32 batch=2^22, 1/2/4/8 GPU"
+            if args.workload == "pmsm_euler_f32" else f"env-steps/sec, {args.workload}",
+            "value": total_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if dtype == torch.float32 else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{reg} {solver} {'fp32' if dtype == torch.float32 else 'fp64'} vmap_sim_ahead, "
+                            f"batch {B} per GPU, {Kc} solver steps per launch, full outputs (obs + state trajectories)",
+                "batch_per_gpu": B, "global_batch": B * world, "chunk_steps": Kc, "semantics": args.semantics,
+                "traj_layout": args.traj_layout, "action_layout": args.action_layout,
+                "parallelism": f"batch-sharded x{world}" + (", all-gather(final obs) overlapped" if gatherer else ""),
+                "outputs_finite": finite,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "sim_ahead_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_step,
+                "algorithmic_bytes_per_launch": algo_bytes, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, reg, solver, dtype, env.tau, Kc)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

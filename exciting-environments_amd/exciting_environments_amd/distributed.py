@@ -1,0 +1,89 @@
+"""Multi-GPU: the batch dimension shards trivially (no environment reads another's state — the reference
+vmaps over axis 0 everywhere, core_env.py:566,612), one process per GPU, zero communication while stepping.
+The only collective is an all-gather of observations (RCCL over xGMI when the backend is "nccl") for a
+consumer that needs the whole batch on every rank; it runs on its own stream so it overlaps the next chunk.
+The reference has no counterpart (single device)."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(global_batch: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous slice [start, stop) of the global batch owned by `rank` (remainder spread over the first ranks)."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of size {world_size}")
+    base, rem = divmod(global_batch, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(global_batch: int, world_size: int):
+    return [shard_range(global_batch, world_size, r)[1] - shard_range(global_batch, world_size, r)[0]
+            for r in range(world_size)]
+
+
+class ObservationGatherer:
+    """All-gather of per-rank observation shards [B_r, ...] into the global [B, ...] array on every rank.
+
+    ``start`` enqueues the collective on a side stream (after the producer stream's work) and returns at once;
+    ``wait`` makes the current stream wait for it. With the "nccl" backend this is one ncclAllGather per call.
+    """
+
+    def __init__(self, global_batch: int, group: Optional[dist.ProcessGroup] = None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.global_batch = global_batch
+        self.sizes = shard_sizes(global_batch, self.world)
+        self.even = len(set(self.sizes)) == 1
+        self._stream = None
+        self._event = None
+
+    def _side_stream(self, device):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+    def _gather(self, local: torch.Tensor, out: torch.Tensor):
+        if self.even:
+            try:
+                dist.all_gather_into_tensor(out, local, group=self.group)
+                return
+            except (RuntimeError, NotImplementedError):
+                pass
+        pad = max(self.sizes)
+        buf = local
+        if local.shape[0] != pad:
+            buf = local.new_zeros((pad,) + tuple(local.shape[1:]))
+            buf[: local.shape[0]] = local
+        parts = [local.new_empty((pad,) + tuple(local.shape[1:])) for _ in range(self.world)]
+        dist.all_gather(parts, buf.contiguous(), group=self.group)
+        off = 0
+        for r, n in enumerate(self.sizes):
+            out[off:off + n] = parts[r][:n]
+            off += n
+
+    def start(self, local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert local.shape[0] == self.sizes[self.rank], "local shard has the wrong batch size"
+        local = local.contiguous()
+        if out is None:
+            out = local.new_empty((self.global_batch,) + tuple(local.shape[1:]))
+        if local.is_cuda:
+            side = self._side_stream(local.device)
+            side.wait_stream(torch.cuda.current_stream(local.device))
+            with torch.cuda.stream(side):
+                self._gather(local, out)
+                local.record_stream(side)
+                out.record_stream(side)
+            self._event = side.record_event()
+        else:
+            self._gather(local, out)
+        return out
+
+    def wait(self):
+        if self._event is not None:
+            torch.cuda.current_stream().wait_event(self._event)
+            self._event = None
