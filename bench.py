@@ -71,6 +71,18 @@ def build_env(args, device, rank):
     return env, state, actions, B, Kc, reg, solver, dtype
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(args, reg, solver, dtype, tau, Kc):
     """The CPU oracle (C/OpenMP restatement pinned to the reference fixtures) timed on this host's cores on a
     bounded sample of the same workload. Reported beside the GPU number; it is a baseline, not the target."""
@@ -95,17 +107,22 @@ def cpu_baseline(args, reg, solver, dtype, tau, Kc):
         st_np[6] = rng.uniform(0, 600, Bc).astype(npdt)
     acts = rng.uniform(-1, 1, (Bc, Kc, env.action_dim)).astype(npdt)
     sem = oracle.SEM_AHEAD if args.semantics == "ahead" else oracle.SEM_STEP
-    oracle.sim_ahead(name, solver, st_np, acts, props, tau, semantics=sem)  # warm-up (thread pool, page faults)
+    threads = host_cores()
+    oracle.set_num_threads(threads)
+    S, O = len(env.STATE_FIELDS), len(env.obs_description)
+    bufs = (np.zeros((Bc, Kc + 1, O), dtype=npdt), [np.zeros((Bc, Kc + 1), dtype=npdt) for _ in range(S)],
+            [np.zeros(Bc, dtype=npdt) for _ in range(S)])
+    oracle.sim_ahead(name, solver, st_np, acts, props, tau, semantics=sem, out=bufs)  # warm-up (thread pool, pages)
     reps, t0 = 0, time.perf_counter()
     while True:
-        _, _, last = oracle.sim_ahead(name, solver, st_np, acts, props, tau, semantics=sem)
-        st_np = last
+        _, _, last = oracle.sim_ahead(name, solver, st_np, acts, props, tau, semantics=sem, out=bufs)
+        st_np = [a.copy() for a in last]
         reps += 1
         el = time.perf_counter() - t0
         if el > args.cpu_seconds or reps >= 10000:
             break
     return {
-        "value": Bc * Kc * reps / el, "unit": "env-steps/s", "cores": oracle.num_threads(), "kind": "port",
+        "value": Bc * Kc * reps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
         "sample": f"oracle/liboracle.so (C+OpenMP restatement, env-major layout) {name} {solver} "
                   f"{np.dtype(npdt).name} B=2^16 x {Kc} steps x {reps} chained chunks, {el:.1f} s",
     }

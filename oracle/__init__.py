@@ -188,7 +188,7 @@ def step(env: str, solver: str, state: Sequence[np.ndarray], action: np.ndarray,
 
 def sim_ahead(env: str, solver: str, state: Sequence[np.ndarray], actions: np.ndarray, props: Props,
               obs_stepsize: float, env_tau: Optional[float] = None, substeps: int = 1, semantics: int = SEM_STEP,
-              control=None, want_states: bool = True):
+              control=None, want_states: bool = True, out=None):
     """vmap_sim_ahead on host arrays in the reference (env-major) layout.
     actions [B,K,A] -> obs [B,N+1,O+nc], states list of [B,N+1], last_state list of [B]."""
     dtype = np.dtype(state[0].dtype)
@@ -203,9 +203,13 @@ def sim_ahead(env: str, solver: str, state: Sequence[np.ndarray], actions: np.nd
     ctl = _make_control(env, control, dtype, B, keep)
     nc = len(control) if control else 0
     st_in = [np.ascontiguousarray(s, dtype=dtype) for s in state]
-    obs = np.empty((B, N + 1, O + nc), dtype=dtype)
-    straj = [np.empty((B, N + 1), dtype=dtype) for _ in range(S)] if want_states else None
-    last = [np.empty(B, dtype=dtype) for _ in range(S)]
+    if out is not None:  # caller-provided (obs, straj, last) buffers: no allocation / page faults per call
+        obs, straj, last = out
+        assert obs.shape == (B, N + 1, O + nc) and obs.dtype == dtype and obs.flags.c_contiguous
+    else:
+        obs = np.empty((B, N + 1, O + nc), dtype=dtype)
+        straj = [np.empty((B, N + 1), dtype=dtype) for _ in range(S)] if want_states else None
+        last = [np.empty(B, dtype=dtype) for _ in range(S)]
     rc = lib().oracle_sim_ahead(
         ctypes.c_int(eid), ctypes.c_int(SOLVER_IDS[solver]), ctypes.c_int(DTYPE_IDS[dtype]), ctypes.c_int64(B),
         ctypes.c_int64(K), ctypes.c_int32(substeps), ctypes.byref(props), ctypes.byref(ctl) if ctl else None,

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run ON THE GPU BOX from the repo root: tools/profile_gpu.sh <tag> [extra bench/probe args...]
+# kernel-trace/--stats and the two PMC counters are collected in separate rocprofv3 runs (gpurun refuses combined
+# trace domains with --pmc). Raw output stays under gpurun_out/ (scratch); the summary goes to profiles/.
+set -u
+TAG=${1:-r01}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 20 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err" || echo "trace run failed"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/tools/traffic_probe.py" "$@" > "$OUT/pmc_fetch.log" 2>&1 || echo "pmc fetch run failed"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/tools/traffic_probe.py" "$@" > "$OUT/pmc_write.log" 2>&1 || echo "pmc write run failed"
+cd "$REPO"
+find "$OUT" -name "*.csv" | head -20

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output into the small files committed under profiles/.
+usage: summarize_profile.py <gpurun_out/prof dir> <profiles dir> <tag> [traffic key]"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+key = sys.argv[4] if len(sys.argv) > 4 else None
+os.makedirs(dst, exist_ok=True)
+
+
+def find(sub, pat):
+    return sorted(glob.glob(os.path.join(src, sub, "**", pat), recursive=True))
+
+
+lines = [f"# rocprofv3 summary {tag}", ""]
+# ---- kernel stats ------------------------------------------------------------------------------
+for f in find("trace", "*kernel_stats.csv"):
+    lines += [f"## kernel-trace --stats ({os.path.basename(f)})", "", "| kernel | calls | total ms | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(f)):
+        name = r.get("Name", "?")
+        short = name if len(name) < 110 else name[:107] + "..."
+        ns = lambda k: float(r.get(k, 0) or 0) / 1e6
+        lines.append(f"| `{short}` | {r.get('Calls')} | {ns('TotalDurationNs'):.3f} | {ns('AverageNs'):.4f} | {ns('MinNs'):.4f} | {ns('MaxNs'):.4f} | {r.get('Percentage')} |")
+    lines.append("")
+# per-dispatch resource usage of the hot kernel
+for f in find("trace", "*kernel_trace.csv"):
+    seen = {}
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "")
+        if "sim_ahead_kernel" in n or "step_kernel" in n:
+            seen[n] = r
+    if seen:
+        lines += ["## dispatch resources (kernel_trace.csv)", "", "| kernel | VGPR | accum VGPR | SGPR | LDS | scratch | workgroup | grid |", "|---|---|---|---|---|---|---|---|"]
+        for n, r in seen.items():
+            lines.append(f"| `{n[:90]}` | {r.get('VGPR_Count')} | {r.get('Accum_VGPR_Count')} | {r.get('SGPR_Count')} | {r.get('LDS_Block_Size')} | {r.get('Scratch_Size')} | {r.get('Workgroup_Size')} | {r.get('Grid_Size')} |")
+        lines.append("")
+
+# ---- PMC ---------------------------------------------------------------------------------------
+pmc = {}
+for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    per = defaultdict(lambda: defaultdict(float))  # kernel -> dispatch -> value
+    for f in find(sub, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            per[r.get("Kernel_Name", "?")][r.get("Dispatch_Id")] += float(r.get("Counter_Value", 0) or 0)
+    pmc[counter] = {k: (sum(v.values()) / len(v), len(v)) for k, v in per.items()}
+if any(pmc.values()):
+    lines += ["## PMC (separate passes; counter unit = KiB per dispatch, averaged over dispatches)", "",
+              "| kernel | dispatches | FETCH_SIZE KiB | WRITE_SIZE KiB |", "|---|---|---|---|"]
+    kernels = sorted(set(pmc.get("FETCH_SIZE", {})) | set(pmc.get("WRITE_SIZE", {})))
+    hot = None
+    calib = None
+    for k in kernels:
+        fz, n1 = pmc.get("FETCH_SIZE", {}).get(k, (float("nan"), 0))
+        wz, n2 = pmc.get("WRITE_SIZE", {}).get(k, (float("nan"), 0))
+        if fz + wz < 1000 and "sim_ahead" not in k:
+            continue
+        lines.append(f"| `{k[:100]}` | {max(n1, n2)} | {fz:.0f} | {wz:.0f} |")
+        if "sim_ahead_kernel" in k:
+            hot = (fz, wz)
+        if "copy" in k.lower() and fz > 2e5:
+            calib = (fz, wz)
+    lines.append("")
+    if calib:
+        gib = float(1 << 20)  # KiB in 1 GiB
+        lines += [f"Calibration copy (1 GiB read + 1 GiB written, 16 B/lane): FETCH_SIZE = {calib[0] / gib:.3f} x bytes read, "
+                  f"WRITE_SIZE = {calib[1] / gib:.3f} x bytes written.", ""]
+    if hot:
+        fcorr = 1.0
+        if calib and calib[0] > 0:
+            fcorr = gib / calib[0]
+        wcorr = 1.0
+        if calib and calib[1] > 0:
+            wcorr = gib / calib[1]
+        hbm = (hot[0] * fcorr + hot[1] * wcorr) * 1024.0
+        lines += [f"sim_ahead_kernel: corrected HBM traffic per launch = ({hot[0]:.0f} KiB x {fcorr:.3f} + {hot[1]:.0f} KiB x {wcorr:.3f}) x 1024 "
+                  f"= {hbm:.4e} bytes.", ""]
+        if key:
+            tpath = os.path.join(dst, "traffic.json")
+            tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            tj[key] = {"hbm_bytes_per_launch": hbm, "fetch_kib": hot[0], "write_kib": hot[1], "fetch_correction": fcorr,
+                       "write_correction": wcorr, "source": f"profiles/{tag}_rocprof_summary.md"}
+            json.dump(tj, open(tpath, "w"), indent=1, sort_keys=True)
+open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
