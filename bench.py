@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--action-layout", default="lane_major", choices=["lane_major", "env_major"])
     ap.add_argument("--gather", default="final", choices=["final", "none"])
     ap.add_argument("--vec", type=int, default=0, help="envs per lane (0 auto)")
+    ap.add_argument("--path", default="sim_ahead", choices=["sim_ahead", "step"],
+                    help="sim_ahead: one persistent launch per bench step (headline); step: one vmap_step launch per bench step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -167,8 +169,15 @@ def main():
     gatherer = ObservationGatherer(B * world) if (world > 1 and args.gather == "final") else None
     gathered = None
 
+    step_actions = [actions[:, k, :].contiguous() for k in range(min(Kc, 8))] if args.path == "step" else None
+    step_count = [0]
+
     def one_step(st):
         nonlocal gathered
+        if args.path == "step":
+            obs, last = env.vmap_step(st, step_actions[step_count[0] % len(step_actions)])
+            step_count[0] += 1
+            return last
         obs, states, last = env.vmap_sim_ahead(st, actions, env.tau, env.tau)
         if gatherer is not None:
             gatherer.wait()  # previous chunk's gather must have drained before its buffer is reused
@@ -206,7 +215,11 @@ def main():
     # events bracket the launch on the launch stream; with the gather enabled the bracket also holds the
     # (asynchronous) enqueue of the collective but no wait for it
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
-    bytes_per_step = _native.sim_ahead_bytes(env.ENV_ID, dtype, True)
+    if args.path == "step":
+        Kc = 1
+        bytes_per_step = _native.step_bytes(env.ENV_ID, dtype)
+    else:
+        bytes_per_step = _native.sim_ahead_bytes(env.ENV_ID, dtype, True)
     algo_bytes = bytes_per_step * B * Kc
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if args.steps else float("nan")
 
@@ -215,7 +228,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            key = f"{args.workload}|B={B}|chunk={Kc}|{args.traj_layout}"
+            key = f"{args.workload}|B={B}|chunk={Kc}|{args.traj_layout}" + ("|step" if args.path == "step" else "")
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
         except Exception:
@@ -238,7 +251,7 @@ def main():
             "dtype": "f32" if dtype == torch.float32 else "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{reg} {solver} {'fp32' if dtype == torch.float32 else 'fp64'} vmap_sim_ahead, "
+                "workload": f"{reg} {solver} {'fp32' if dtype == torch.float32 else 'fp64'} vmap_{args.path}, "
                             f"batch {B} per GPU, {Kc} solver steps per launch, full outputs (obs + state trajectories)",
                 "batch_per_gpu": B, "global_batch": B * world, "chunk_steps": Kc, "semantics": args.semantics,
                 "traj_layout": args.traj_layout, "action_layout": args.action_layout,
@@ -248,7 +261,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "sim_ahead_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_step,
+                "kernel": "sim_ahead_kernel" if args.path == "sim_ahead" else "step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_step,
                 "algorithmic_bytes_per_launch": algo_bytes, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
         }

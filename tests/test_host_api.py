@@ -1,0 +1,245 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol include/excenv.h declares,
+and the Python mirror keeps the reference's constructor / attribute / error behaviour
+(reference tests: tests/envs/test_core_functions.py, tests/envs/*/test_*.py default/custom initialisation).
+No kernel is launched here."""
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import exciting_environments_amd as excenvs
+from exciting_environments_amd import EnvironmentRegistry, MinMaxNormalization, _native
+from exciting_environments_amd.tree import tree_structure
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+envs_to_test = list(EnvironmentRegistry)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "excenv.h")).read()
+    declared = set(re.findall(r"\b(excenv_[a-z_0-9]+)\s*\(", hdr))
+    assert {"excenv_step", "excenv_sim_ahead", "excenv_last_error", "excenv_env_dims", "excenv_abi_version"} <= declared
+    lib = ctypes.CDLL(_native.library_path())
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"libexcenv_hip.so does not export {sym}"
+    assert _native.lib().excenv_abi_version() == 1
+
+
+def test_env_dims_and_algorithmic_bytes():
+    dims = {0: (2, 1, 2, 3), 1: (2, 1, 2, 3), 2: (4, 1, 4, 6), 3: (4, 1, 4, 9), 4: (1, 1, 1, 4), 5: (7, 2, 8, 7)}
+    for e, d in dims.items():
+        assert _native.env_dims(e) == d
+    # PMSM fp32 96 B (step) / 68 B (sim_ahead, full outputs) / 40 B (obs only)
+    assert _native.step_bytes(5, torch.float32) == 96
+    assert _native.sim_ahead_bytes(5, torch.float32, True) == 68
+    assert _native.sim_ahead_bytes(5, torch.float32, False) == 40
+    assert _native.sim_ahead_bytes(0, torch.float32, True) == 20
+    assert _native.sim_ahead_bytes(1, torch.float64, True) == 40
+    with pytest.raises(RuntimeError, match="bad env id"):
+        _native.env_dims(17)
+
+
+def test_abi_argument_validation_without_gpu():
+    """Bad enums / NULL pointers are rejected by the C ABI before any HIP call."""
+    lib = _native.lib()
+    p = _native.Props()
+    rc = lib.excenv_step(99, 0, 0, ctypes.c_int64(4), ctypes.byref(p), None, ctypes.c_double(1e-4), None, None, None, None, None)
+    assert rc == -1 and b"bad env id" in lib.excenv_last_error()
+    rc = lib.excenv_step(0, 7, 0, ctypes.c_int64(4), ctypes.byref(p), None, ctypes.c_double(1e-4), None, None, None, None, None)
+    assert rc == -1 and b"bad solver id" in lib.excenv_last_error()
+    rc = lib.excenv_step(0, 0, 0, ctypes.c_int64(4), ctypes.byref(p), None, ctypes.c_double(1e-4), None, None, None, None, None)
+    assert rc == -2
+    rc = lib.excenv_sim_ahead(0, 0, 0, ctypes.c_int64(4), ctypes.c_int64(-1), 1, ctypes.byref(p), None, ctypes.c_double(1e-4),
+                              ctypes.c_double(1e-4), None, None, 0, None, None, 0, None, 0, None)
+    assert rc == -1
+    assert lib.excenv_set_tuning(5, 1) == -1
+
+
+@pytest.mark.parametrize("env_type", envs_to_test)
+@pytest.mark.parametrize("tau", [1e-4, 1e-5])
+def test_tau(env_type, tau):
+    assert env_type.make(tau=tau).tau == tau
+
+
+def test_default_parameters_match_reference():
+    """Literal defaults of the reference constructors (e.g. pendulum_env.py:84-97, motor_parameters.py:124-149)."""
+    pend = EnvironmentRegistry.PENDULUM.make()
+    assert (pend.batch_size, pend.tau) == (8, 1e-4)
+    sp = pend.env_properties.static_params
+    assert (sp.g, sp.l, sp.m) == (9.81, 2, 1)
+    pn = pend.env_properties.physical_normalizations
+    assert (pn.theta.min, pn.theta.max, pn.omega.min, pn.omega.max) == (-math.pi, math.pi, -10, 10)
+    assert (pend.env_properties.action_normalizations.torque.min, pend.env_properties.action_normalizations.torque.max) == (-20, 20)
+    msd = EnvironmentRegistry.MASS_SPRING_DAMPER.make()
+    assert (msd.env_properties.static_params.k, msd.env_properties.static_params.d, msd.env_properties.static_params.m) == (100, 1, 1)
+    cp = EnvironmentRegistry.CART_POLE.make()
+    assert cp.tau == 2e-2 and cp.env_properties.static_params.mu_p == 0.000002 and cp.env_properties.physical_normalizations.deflection.max == 2.4
+    ac = EnvironmentRegistry.ACROBOT.make()
+    assert ac.tau == 1e-3 and ac.env_properties.static_params.I_1 == 1.3 and len(ac.PARAM_FIELDS) == 9
+    ft = EnvironmentRegistry.FLUID_TANK.make()
+    assert (ft.batch_size, ft.tau) == (1, 1e-3) and ft.env_properties.static_params.orifice_area == math.pi * 0.1**2
+    pm = EnvironmentRegistry.PMSM.make()
+    sp = pm.env_properties.static_params
+    assert (sp.p, sp.r_s, sp.l_d, sp.l_q, sp.psi_p, sp.u_dc, sp.deadtime) == (3, 15e-3, 0.37e-3, 1.2e-3, 65.6e-3, 400, 1)
+    assert pm.env_properties.physical_normalizations.omega_el.max == 3 * 11000 * 2 * math.pi / 60
+    assert pm.env_properties.physical_normalizations.i_d.min == -250 and pm.env_properties.saturated is False
+    for variant in excenvs.MotorVariant:
+        env = EnvironmentRegistry.PMSM.make(motor_variant=variant)
+        want = variant.get_params().static_params
+        assert all(getattr(env.env_properties.static_params, k) == v for k, v in want.items())
+    with pytest.raises(ValueError, match="not allowed for saturated"):
+        EnvironmentRegistry.PMSM.make(saturated=True)
+
+
+def test_custom_initialization_keeps_arrays_and_marks_axes():
+    """reference tests/envs/pendulum/test_pendulum.py:72-129: per-env arrays are stored as given; in_axes 0 / None."""
+    B = 4
+    phys = {"theta": MinMaxNormalization(min=np.repeat(-np.pi / 2, B), max=np.pi / 2), "omega": MinMaxNormalization(min=-5, max=3)}
+    act = {"torque": MinMaxNormalization(min=-10, max=10)}
+    params = {"l": torch.ones(B), "g": 9.81, "m": 1}
+    env = EnvironmentRegistry.PENDULUM.make(batch_size=B, static_params=params, physical_normalizations=phys, action_normalizations=act)
+    assert env.env_properties.static_params.l is params["l"]
+    assert env.env_properties.physical_normalizations.theta.min is phys["theta"].min
+    ax = env.in_axes_env_properties
+    assert ax.static_params.l == 0 and ax.static_params.g is None
+    assert ax.physical_normalizations.theta.min == 0 and ax.physical_normalizations.theta.max is None
+    assert ax.action_normalizations.torque.min is None
+    # an array whose leading dimension is not batch_size is a broadcast leaf (core_env.py:268-272)
+    env2 = EnvironmentRegistry.PENDULUM.make(batch_size=B, static_params={"l": np.ones(3), "g": 9.81, "m": 1})
+    assert env2.in_axes_env_properties.static_params.l is None
+
+
+def test_property_type_errors():
+    with pytest.raises(ValueError, match="but list is given"):
+        EnvironmentRegistry.PENDULUM.make(static_params={"l": [1.0, 2.0], "g": 9.81, "m": 1})
+    with pytest.raises(ValueError, match="needs to be a scalar"):
+        EnvironmentRegistry.PENDULUM.make(static_params={"l": "long", "g": 9.81, "m": 1})
+    with pytest.raises(TypeError):
+        EnvironmentRegistry.PENDULUM.make(solver="euler")
+    with pytest.raises(TypeError):
+        EnvironmentRegistry.PENDULUM.make(dtype=torch.float16)
+
+
+@pytest.mark.parametrize("env_type", envs_to_test)
+def test_reset(env_type):
+    """reference tests/envs/test_core_functions.py:25-52."""
+    B = 4
+    env = env_type.make(batch_size=B, device="cpu")
+    obs, state = env.reset(env.env_properties, 1234)
+    assert obs.shape == env.obs_description.shape and type(state) == env.State
+    obs, state = env.reset(env.env_properties)
+    assert obs.shape == env.obs_description.shape and type(state) == env.State
+    obs, state = env.vmap_reset(1234)
+    assert obs.shape == (B, len(env.obs_description)) and type(state) == env.State
+    assert float(obs.abs().max()) <= 1.0 + 1e-6
+    obs, state = env.vmap_reset()
+    assert obs.shape == (B, len(env.obs_description)) and type(state) == env.State
+    assert not bool(state.additions.active_solver_state.any())
+    assert bool(torch.isnan(state.PRNGKey).all()) and bool(torch.isnan(getattr(state.reference, env.STATE_FIELDS[0])).all())
+    obs2, state2 = env.vmap_reset(initial_state=state)
+    assert torch.equal(obs, obs2)
+    with pytest.raises(AssertionError, match="same dataclass structure"):
+        env.vmap_reset(initial_state=state.physical_state)
+
+
+def test_default_reset_states_in_physical_units():
+    """SURVEY.md §8 a11."""
+    val = lambda env, n: float(getattr(env.vmap_reset()[1].physical_state, n)[0])
+    pend = EnvironmentRegistry.PENDULUM.make(device="cpu", dtype=torch.float64)
+    assert val(pend, "theta") == math.pi and val(pend, "omega") == 0.0
+    cp = EnvironmentRegistry.CART_POLE.make(device="cpu", dtype=torch.float64)
+    assert val(cp, "theta") == math.pi and val(cp, "deflection") == 0.0
+    ft = EnvironmentRegistry.FLUID_TANK.make(device="cpu", dtype=torch.float64)
+    assert val(ft, "height") == 1.5
+    pm = EnvironmentRegistry.PMSM.make(device="cpu", dtype=torch.float64)
+    assert val(pm, "i_d") == -125.0 and abs(val(pm, "omega_el") - 3 * 11000 * 2 * math.pi / 60 / 2) < 1e-9
+    obs, _ = pm.vmap_reset()
+    assert obs[0].tolist() == [0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("env_type", envs_to_test)
+def test_gen_observation_gen_state(env_type):
+    """reference tests/envs/test_core_functions.py:55-77: obs -> state -> obs round trip is exact."""
+    env = env_type.make(batch_size=4, device="cpu", dtype=torch.float64)
+    obs, state = env.reset(env.env_properties)
+    assert torch.equal(obs, env.generate_observation(state, env.env_properties))
+    assert torch.equal(obs, env.generate_observation(env.generate_state_from_observation(obs, env.env_properties), env.env_properties))
+    obs, state = env.vmap_reset()
+    assert torch.equal(obs, env.generate_observation(env.vmap_generate_state_from_observation(obs), env.env_properties))
+
+
+def test_control_state_extends_observation():
+    env = EnvironmentRegistry.PENDULUM.make(batch_size=3, control_state=["theta"], device="cpu")
+    assert list(env.obs_description) == ["theta", "omega", "theta_ref"]
+    obs, state = env.vmap_reset()
+    assert obs.shape == (3, 3) and bool(torch.isnan(obs[:, 2]).all())
+    pm = EnvironmentRegistry.PMSM.make(batch_size=3, control_state=["i_d", "i_q"], device="cpu")
+    assert pm.vmap_reset()[0].shape == (3, 10) and list(pm.obs_description[-2:]) == ["i_d_ref", "i_q_ref"]
+
+
+@pytest.mark.parametrize("env_type", envs_to_test)
+def test_shape_assertions_fire_before_any_kernel(env_type):
+    """Messages of core_env.py:546-563, 591-609."""
+    B = 4
+    env = env_type.make(batch_size=B, device="cpu")
+    _, state = env.vmap_reset()
+    with pytest.raises(AssertionError, match=r"The action needs to be of shape \(batch_size, action_dim\)"):
+        env.vmap_step(state, torch.ones(B + 1, env.action_dim))
+    with pytest.raises(AssertionError, match="three dimensions"):
+        env.vmap_sim_ahead(state, torch.ones(B, env.action_dim), env.tau, env.tau)
+    with pytest.raises(AssertionError, match="does not correspond to the batch size"):
+        env.vmap_sim_ahead(state, torch.ones(B + 1, 5, env.action_dim), env.tau, env.tau)
+    with pytest.raises(AssertionError, match="does not correspond to the action dim"):
+        env.vmap_sim_ahead(state, torch.ones(B, 5, env.action_dim + 1), env.tau, env.tau)
+    with pytest.raises(AssertionError, match="greater or equal to the observation stepsize"):
+        env.vmap_sim_ahead(state, torch.ones(B, 5, env.action_dim), 2 * env.tau, env.tau)
+    bad = env.State(physical_state=env.PhysicalState(**{n: torch.zeros(B + 2) for n in env.STATE_FIELDS}),
+                    PRNGKey=state.PRNGKey, additions=state.additions, reference=state.reference)
+    with pytest.raises(AssertionError, match="physical state needs to be of shape"):
+        env.vmap_step(bad, torch.ones(B, env.action_dim))
+    _, s1 = env.reset(env.env_properties)
+    with pytest.raises(AssertionError, match=r"shape \(action_dim,\)"):
+        env.step(s1, torch.ones(env.action_dim + 1), env.env_properties)
+
+
+def test_no_cpu_fallback():
+    """The product path fails loudly without a HIP device instead of computing on the CPU."""
+    env = EnvironmentRegistry.PENDULUM.make(batch_size=2, device="cpu")
+    _, state = env.vmap_reset()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        env.vmap_step(state, torch.ones(2, 1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        env.vmap_sim_ahead(state, torch.ones(2, 3, 1), env.tau, env.tau)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "exciting-environments_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h")):
+                txt = open(os.path.join(d, f)).read()
+                assert "import oracle" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("oracle/oracle_body.inc rk_step", ""), f
+
+
+def test_tree_structure_helpers():
+    env = EnvironmentRegistry.ACROBOT.make(batch_size=2, device="cpu")
+    _, a = env.vmap_reset()
+    _, b = env.vmap_reset(3)
+    assert tree_structure(a) == tree_structure(b)
+    assert tree_structure(a) != tree_structure(a.physical_state)
+
+
+def test_sim_properties_json_round_trip(tmp_path):
+    params = {"g": 9.81, "l": 2, "m": 1}
+    an = {"torque": MinMaxNormalization(-20, 20)}
+    pn = {"theta": MinMaxNormalization(-math.pi, math.pi), "omega": MinMaxNormalization(-10, 10)}
+    f = tmp_path / "p.json"
+    excenvs.dump_sim_properties_to_json(params, an, pn, 1e-4, f)
+    p2, a2, n2, tau = excenvs.load_sim_properties_from_json(f)
+    assert p2 == params and a2 == an and n2 == pn and tau == 1e-4
+    g = excenvs.load_sim_properties_from_json(os.path.join(ROOT, "tests", "golden", "pmsm", "sim_properties.json"))
+    assert g[0]["deadtime"] == 1 and g[3] == 1e-4

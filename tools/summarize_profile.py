@@ -59,33 +59,33 @@ if any(pmc.values()):
     for k in kernels:
         fz, n1 = pmc.get("FETCH_SIZE", {}).get(k, (float("nan"), 0))
         wz, n2 = pmc.get("WRITE_SIZE", {}).get(k, (float("nan"), 0))
-        if fz + wz < 1000 and "sim_ahead" not in k:
+        if not (fz + wz >= 1000 or "sim_ahead" in k or "step_kernel" in k):
             continue
         lines.append(f"| `{k[:100]}` | {max(n1, n2)} | {fz:.0f} | {wz:.0f} |")
-        if "sim_ahead_kernel" in k:
-            hot = (fz, wz)
-        if "copy" in k.lower() and fz > 2e5:
+        if "sim_ahead_kernel" in k or "step_kernel" in k:
+            hot = (fz, wz, k)
+        if "trunc" in k.lower():
             calib = (fz, wz)
     lines.append("")
+    gib = float(1 << 20)  # KiB in 1 GiB
     if calib:
-        gib = float(1 << 20)  # KiB in 1 GiB
-        lines += [f"Calibration copy (1 GiB read + 1 GiB written, 16 B/lane): FETCH_SIZE = {calib[0] / gib:.3f} x bytes read, "
-                  f"WRITE_SIZE = {calib[1] / gib:.3f} x bytes written.", ""]
+        lines += [f"Calibration (`torch.trunc` over 2^28 fp32: 1 GiB read + 1 GiB written, 16 B/lane): FETCH_SIZE reports "
+                  f"{calib[0] / gib:.3f} x the bytes read, WRITE_SIZE {calib[1] / gib:.3f} x the bytes written "
+                  "(MI355X_MICROARCH.md §HBM: FETCH_SIZE counts exactly 1/2 of a wide coalesced read stream on gfx950, "
+                  "WRITE_SIZE is exact).", ""]
     if hot:
-        fcorr = 1.0
-        if calib and calib[0] > 0:
-            fcorr = gib / calib[0]
-        wcorr = 1.0
-        if calib and calib[1] > 0:
-            wcorr = gib / calib[1]
-        hbm = (hot[0] * fcorr + hot[1] * wcorr) * 1024.0
-        lines += [f"sim_ahead_kernel: corrected HBM traffic per launch = ({hot[0]:.0f} KiB x {fcorr:.3f} + {hot[1]:.0f} KiB x {wcorr:.3f}) x 1024 "
+        # correction prescribed by the guide: double FETCH_SIZE, take WRITE_SIZE as is
+        hbm = (2.0 * hot[0] + hot[1]) * 1024.0
+        lines += [f"`{hot[2][:60]}...`: HBM traffic per launch = (2 x {hot[0]:.0f} KiB + {hot[1]:.0f} KiB) x 1024 "
                   f"= {hbm:.4e} bytes.", ""]
         if key:
             tpath = os.path.join(dst, "traffic.json")
             tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-            tj[key] = {"hbm_bytes_per_launch": hbm, "fetch_kib": hot[0], "write_kib": hot[1], "fetch_correction": fcorr,
-                       "write_correction": wcorr, "source": f"profiles/{tag}_rocprof_summary.md"}
+            tj[key] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib": hot[0], "write_size_kib": hot[1],
+                       "fetch_correction": 2.0, "write_correction": 1.0,
+                       "calibration_fetch_ratio": calib[0] / gib if calib else None,
+                       "calibration_write_ratio": calib[1] / gib if calib else None,
+                       "source": f"profiles/{tag}_rocprof_summary.md"}
             json.dump(tj, open(tpath, "w"), indent=1, sort_keys=True)
 open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -29,7 +29,7 @@ dev = torch.device("cuda", 0)
 src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
 dst = torch.empty_like(src)
 for _ in range(3):
-    dst.copy_(src)
+    torch.trunc(src, out=dst)  # a kernel name nothing else in this process uses ("trunc")
 torch.cuda.synchronize()
 del src, dst
 env, state, actions, B, Kc, reg, solver, dtype = bench.build_env(a, dev, 0)
