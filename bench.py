@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--action-layout", default="lane_major", choices=["lane_major", "env_major"])
     ap.add_argument("--gather", default="final", choices=["final", "none"])
     ap.add_argument("--vec", type=int, default=0, help="envs per lane (0 auto)")
+    ap.add_argument("--lds-pad", type=int, default=0, help="dynamic LDS bytes per workgroup (occupancy cap experiment)")
     ap.add_argument("--path", default="sim_ahead", choices=["sim_ahead", "step"],
                     help="sim_ahead: one persistent launch per bench step (headline); step: one vmap_step launch per bench step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -166,6 +167,8 @@ def main():
     env, state, actions, B, Kc, reg, solver, dtype = build_env(args, device, rank)
     if args.vec:
         _native.set_tuning(0, args.vec)
+    if args.lds_pad:
+        _native.set_tuning(1, args.lds_pad)
     gatherer = ObservationGatherer(B * world) if (world > 1 and args.gather == "final") else None
     gathered = None
 

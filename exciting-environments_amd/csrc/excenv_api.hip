@@ -31,6 +31,7 @@ static const EnvVTable* table(int env) {
 }
 
 static int g_vec_pref = 0;
+static int g_lds_pad = 0;
 
 static int check_common(const char* fn, int env, int solver, int dtype, int64_t B) {
   if (!table(env)) { set_error("%s: bad env id %d", fn, env); return EXCENV_EINVAL; }
@@ -88,10 +89,9 @@ int64_t excenv_sim_ahead_bytes(int env, int dtype, int with_state_traj) {
 /* tuning knob (not part of the reference surface): key 0 = envs per lane for lane-major trajectories
  * (0 auto, 1/2/4 forced). Returns the previous value. */
 int excenv_set_tuning(int key, int value) {
-  if (key != 0) return EXCENV_EINVAL;
-  int old = g_vec_pref;
-  g_vec_pref = value;
-  return old;
+  if (key == 0) { int old = g_vec_pref; g_vec_pref = value; return old; }
+  if (key == 1) { int old = g_lds_pad; g_lds_pad = value < 0 ? 0 : value; return old; }
+  return EXCENV_EINVAL;
 }
 
 int excenv_step(int env, int solver, int dtype, int64_t B, const excenv_props_t* props,
@@ -120,7 +120,7 @@ int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
   if (!props || !state_in || (!actions && K > 0) || !obs_traj || !last_state) { set_error("excenv_sim_ahead: NULL argument"); return EXCENV_ENULL; }
   if (int rc = check_control("excenv_sim_ahead", env, control)) return rc;
   SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, actions, action_layout,
-             obs_traj, state_traj, traj_layout, last_state, semantics, g_vec_pref, (hipStream_t)stream};
+             obs_traj, state_traj, traj_layout, last_state, semantics, g_vec_pref, g_lds_pad, (hipStream_t)stream};
   return table(env)->sim(sc);
 }
 

@@ -6,7 +6,13 @@
 
 namespace excenv {
 
-constexpr int BLOCK = 256;
+#ifndef EXCENV_BLOCK
+#define EXCENV_BLOCK 256
+#endif
+#ifndef EXCENV_NT_STORES
+#define EXCENV_NT_STORES 1
+#endif
+constexpr int BLOCK = EXCENV_BLOCK;
 
 // Property leaves in kernel-argument order: P statics, S mins, S maxs, A mins, A maxs.
 template <typename T, class M> struct KProps {
@@ -103,6 +109,23 @@ template <typename T, int V> __device__ __forceinline__ void store_v(T* p, const
     for (int j = 0; j < V; ++j) e[j] = in[j];
     *reinterpret_cast<VT*>(p) = v;
   }
+}
+
+// Trajectory rows are written once and never read back by the kernel: optional streaming (nt) stores.
+template <typename T, int V> __device__ __forceinline__ void store_stream(T* p, const T (&in)[V]) {
+#if EXCENV_NT_STORES
+  if constexpr (V == 1) {
+    __builtin_nontemporal_store(in[0], p);
+  } else {
+    typedef T NVT __attribute__((ext_vector_type(V)));  // the builtin wants a native clang vector
+    NVT v;
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = in[j];
+    __builtin_nontemporal_store(v, reinterpret_cast<NVT*>(p));
+  }
+#else
+  store_v<T, V>(p, in);
+#endif
 }
 
 // Row-major row of N values per lane (obs[B][O], action[B][A]): widest power-of-two chunks up to 16 bytes.
@@ -261,7 +284,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
         T tmp[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) tmp[v] = ob[v][q];
-        store_v<T, V>(orow + q * ka.o_sc + o_lane, tmp);
+        store_stream<T, V>(orow + q * ka.o_sc + o_lane, tmp);
       }
       if (ka.n_control > 0) {  // reference-tracking columns (constant along the trajectory)
         for (int j = 0; j < ka.n_control; ++j) {
@@ -284,7 +307,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
           T tmp[V];
 #pragma unroll
           for (int v = 0; v < V; ++v) tmp[v] = sv[v][j];
-          store_v<T, V>(ka.straj[j] + s_blk + n * ka.s_sk + s_lane, tmp);
+          store_stream<T, V>(ka.straj[j] + s_blk + n * ka.s_sk + s_lane, tmp);
         }
       }
     }

@@ -39,6 +39,7 @@ struct SimCall {
   void* const* last_state;
   int semantics;
   int vec_pref;  // 0 auto, else forced envs-per-lane (1, 2, 4)
+  int lds_pad;   // dynamic LDS bytes per workgroup (occupancy shaping experiments; 0 = none)
   hipStream_t stream;
 };
 
@@ -144,14 +145,14 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
   if (batched) {
-    hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, true, 1>), grid, block, 0, sc.stream, ka);
+    hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, true, 1>), grid, block, sc.lds_pad, sc.stream, ka);
     return;
   }
   if constexpr (sizeof(T) == 4) {
-    if (V == 4) { hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 4>), grid, block, 0, sc.stream, ka); return; }
+    if (V == 4) { hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 4>), grid, block, sc.lds_pad, sc.stream, ka); return; }
   }
-  if (V == 2) { hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 2>), grid, block, 0, sc.stream, ka); return; }
-  hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 1>), grid, block, 0, sc.stream, ka);
+  if (V == 2) { hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 2>), grid, block, sc.lds_pad, sc.stream, ka); return; }
+  hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 1>), grid, block, sc.lds_pad, sc.stream, ka);
 }
 
 template <class M, typename T> static int launch_sim(const SimCall& sc) {

@@ -17,7 +17,8 @@ LAYOUT_ENV_MAJOR, LAYOUT_LANE_MAJOR = 0, 1
 SEM_STEP, SEM_AHEAD = 0, 1
 F32, F64 = 0, 1
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libexcenv_hip.so")
+_LIB_PATH = os.environ.get(  # EXCENV_HIP_LIB: A/B-test another build of the same library (tuning experiments)
+    "EXCENV_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libexcenv_hip.so"))
 
 
 class Param(ctypes.Structure):

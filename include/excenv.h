@@ -137,6 +137,8 @@ int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
 
 /* ---- tuning (no reference counterpart) -------------------------------------------------------
  * key 0: environments per lane for lane-major trajectories (0 = auto, 1/2/4 = forced). Process-wide.
+ * key 1: dynamic LDS bytes requested per sim_ahead workgroup (the kernels use no LDS; this only caps the
+ *        number of resident workgroups per CU for occupancy experiments; 0 = none).
  * Returns the previous value, or EXCENV_EINVAL for an unknown key. */
 int excenv_set_tuning(int key, int value);
 

@@ -56,7 +56,7 @@ def test_abi_argument_validation_without_gpu():
     rc = lib.excenv_sim_ahead(0, 0, 0, ctypes.c_int64(4), ctypes.c_int64(-1), 1, ctypes.byref(p), None, ctypes.c_double(1e-4),
                               ctypes.c_double(1e-4), None, None, 0, None, None, 0, None, 0, None)
     assert rc == -1
-    assert lib.excenv_set_tuning(5, 1) == -1
+    assert lib.excenv_set_tuning(5, 1) == -1 and lib.excenv_set_tuning(1, 0) == 0
 
 
 @pytest.mark.parametrize("env_type", envs_to_test)
