@@ -1,0 +1,159 @@
+"""BASELINE.json configurations at their full sizes, checked through size-independent properties:
+replica consistency (a small oracle-verified set of environments tiled across the whole batch must give the same
+bits in every tile), chunk chaining (last_state -> init_state, the reference's continuation mechanism,
+core_env.py:484-486), and a closed-form solution for the linear system. Needs an MI355X (``-m gpu``)."""
+import numpy as np
+import pytest
+import torch
+from scipy.linalg import expm
+
+import oracle
+from helpers import make_env, random_state, spec_of, to_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _tile_state(env, st_small, reps):
+    _, state = env.vmap_reset()
+    for n, v in zip(env.STATE_FIELDS, st_small):
+        setattr(state.physical_state, n, torch.as_tensor(v, dtype=env.dtype, device=env.device).repeat(reps))
+    return state
+
+
+def _tile_actions(env, acts_small, reps):
+    K = acts_small.shape[1]
+    buf = env.new_actions_buffer(K)  # [B, K, A] view over lane-major memory
+    small = torch.as_tensor(acts_small, dtype=env.dtype, device=env.device)  # [T, K, A]
+    T = small.shape[0]
+    base = buf.permute(1, 2, 0)  # [K, A, B] contiguous
+    base.view(K, env.action_dim, reps, T).copy_(small.permute(1, 2, 0)[:, :, None, :].expand(K, env.action_dim, reps, T))
+    return buf
+
+
+def _all_tiles_equal(x, T):
+    """x: [B, ...] with B = reps*T -> every tile of T consecutive envs equals the first one, bit for bit."""
+    tiles = x.reshape((-1, T) + tuple(x.shape[1:]))
+    return bool((tiles == tiles[:1]).all()) or bool(((tiles == tiles[:1]) | (tiles.isnan() & tiles[:1].isnan())).all())
+
+
+def test_readme_plumbing_config_c1():
+    """configs[0] (README.md:15-33): Pendulum, Euler, tau=2e-2, batch 5, 1000 steps -> five identical trajectories."""
+    spec = spec_of("pendulum")
+    spec["tau"] = 2e-2
+    spec["act_norm"]["torque"] = (-15, 15)
+    env, props, keep, _ = make_env("pendulum", 5, torch.float32, spec=spec)
+    obs, state = env.vmap_reset()
+    actions = torch.linspace(-1, 1, 1000, device=env.device)[None, :, None].repeat(5, 1, 1)
+    stepped = [obs]
+    for k in range(1000):
+        obs, state = env.vmap_step(state, actions[:, k, :])
+        stepped.append(obs)
+    stepped = torch.stack(stepped, dim=1)
+    assert stepped.shape == (5, 1001, 2)
+    assert bool((stepped == stepped[:1]).all())
+    st0 = [np.full(5, np.pi, dtype=np.float32), np.zeros(5, dtype=np.float32)]
+    o_ref, _, _ = oracle.sim_ahead("pendulum", "euler", st0, actions.cpu().numpy(), props, 2e-2, semantics=oracle.SEM_STEP)
+    d = np.abs(stepped.cpu().numpy() - o_ref)
+    d[..., 0] = np.minimum(d[..., 0], 2 - d[..., 0])
+    assert d.max() < 2e-4  # fp32, 1000 steps at tau = 2e-2: sin() ulps amplified along the swing
+    _, s0 = env.vmap_reset()
+    env.sim_ahead_semantics = "step"
+    o_sa, _, _ = env.vmap_sim_ahead(s0, actions, env.tau, env.tau)
+    assert torch.equal(o_sa[:, 1:], stepped[:, 1:])
+
+
+def test_pmsm_euler_fp32_batch_2pow22_config_c3():
+    """configs[2]: PMSM Euler fp32, B = 2^22, one 100-step chunk with full outputs."""
+    B, K, T = 1 << 22, 100, 1024
+    env, props_small, keep, spec = make_env("pmsm", B, torch.float32)
+    _, props_T, keepT, _ = make_env("pmsm", T, torch.float32, device="cpu")
+    st_small = random_state("pmsm", T, np.float32, spec, seed=101)
+    acts_small = np.random.default_rng(102).uniform(-1, 1, (T, K, 2)).astype(np.float32)
+    state = _tile_state(env, st_small, B // T)
+    actions = _tile_actions(env, acts_small, B // T)
+    assert torch.equal(actions[:T].cpu(), torch.as_tensor(acts_small)) and torch.equal(actions[B - T:].cpu(), torch.as_tensor(acts_small))
+
+    env.sim_ahead_semantics = "ahead"
+    obs, states, last = env.vmap_sim_ahead(state, actions, env.tau, env.tau)
+    assert obs.shape == (B, K + 1, 8) and states.physical_state.i_d.shape == (B, K + 1)
+    assert _all_tiles_equal(obs, T)
+    for n in env.STATE_FIELDS:
+        assert _all_tiles_equal(getattr(states.physical_state, n), T), n
+        assert torch.equal(getattr(last.physical_state, n), getattr(states.physical_state, n)[:, -1])
+    o_ref, s_ref, _ = oracle.sim_ahead("pmsm", "euler", st_small, acts_small, props_T, spec["tau"], semantics=oracle.SEM_AHEAD)
+    assert np.allclose(obs[:T].cpu().numpy(), o_ref, rtol=1e-5, atol=1e-5)
+    assert bool(torch.isfinite(obs).all())
+    del obs, states
+
+    # chunk chaining, SEM_STEP: 100 steps == 50 + 50 through last_state, bit for bit
+    env.sim_ahead_semantics = "step"
+    o_full, _, l_full = env.vmap_sim_ahead(state, actions, env.tau, env.tau)
+    tail = o_full[:, 50:].clone()
+    del o_full
+    a1, a2 = env.new_actions_buffer(50), env.new_actions_buffer(50)
+    a1.copy_(actions[:, :50])
+    a2.copy_(actions[:, 50:])
+    o1, _, l1 = env.vmap_sim_ahead(state, a1, env.tau, env.tau)
+    del o1
+    o2, _, l2 = env.vmap_sim_ahead(l1, a2, env.tau, env.tau)
+    assert torch.equal(o2, tail)
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(l2.physical_state, n), getattr(l_full.physical_state, n))
+
+
+def test_pendulum_euler_fp32_batch_2pow20_config_c2():
+    """configs[1]: Pendulum Euler fp32, B = 2^20, tau = 2e-2, one 1000-step chunk."""
+    B, K, T = 1 << 20, 1000, 512
+    spec = spec_of("pendulum")
+    spec["tau"] = 2e-2
+    env, _, _, _ = make_env("pendulum", B, torch.float32, spec=spec)
+    _, props_T, keepT, _ = make_env("pendulum", T, torch.float32, spec=spec, device="cpu")
+    rng = np.random.default_rng(111)
+    st_small = [rng.uniform(-np.pi, np.pi, T).astype(np.float32), rng.uniform(-1, 1, T).astype(np.float32)]
+    acts_small = rng.uniform(-1, 1, (T, K, 1)).astype(np.float32)
+    state = _tile_state(env, st_small, B // T)
+    actions = _tile_actions(env, acts_small, B // T)
+    env.sim_ahead_semantics = "step"
+    obs, states, last = env.vmap_sim_ahead(state, actions, env.tau, env.tau)
+    assert obs.shape == (B, K + 1, 2)
+    assert _all_tiles_equal(obs, T) and _all_tiles_equal(states.physical_state.theta, T)
+    theta = states.physical_state.theta
+    assert float(theta.min()) >= -np.pi - 1e-6 and float(theta.max()) <= np.pi + 1e-6  # wrapped every step
+    o_ref, _, _ = oracle.sim_ahead("pendulum", "euler", st_small, acts_small[:, :50], props_T, 2e-2, semantics=oracle.SEM_STEP)
+    d = np.abs(obs[:T, :51].cpu().numpy() - o_ref)
+    d[..., 0] = np.minimum(d[..., 0], 2 - d[..., 0])
+    assert d.max() < 1e-5
+
+
+def test_msd_tsit5_fp64_batch_2pow20_config_c4():
+    """configs[3]: MassSpringDamper Tsit5 fp64, B = 2^20, 500-step chunk — tolerance check against the closed-form
+    (matrix-exponential) solution for piecewise-constant force, and bit-exactness against the CPU oracle."""
+    B, K, T = 1 << 20, 500, 256
+    env, _, _, spec = make_env("mass_spring_damper", B, torch.float64, "tsit5")
+    _, props_T, keepT, _ = make_env("mass_spring_damper", T, torch.float64, "tsit5", device="cpu")
+    rng = np.random.default_rng(121)
+    st_small = [rng.uniform(-1, 1, T), rng.uniform(-1, 1, T)]
+    acts_small = rng.uniform(-1, 1, (T, K, 1))
+    state = _tile_state(env, st_small, B // T)
+    actions = _tile_actions(env, acts_small, B // T)
+    env.sim_ahead_semantics = "step"
+    obs, states, last = env.vmap_sim_ahead(state, actions, env.tau, env.tau)
+    assert obs.shape == (B, K + 1, 2)
+    assert _all_tiles_equal(obs, T)
+    o_ref, s_ref, _ = oracle.sim_ahead("mass_spring_damper", "tsit5", st_small, acts_small, props_T, spec["tau"],
+                                       semantics=oracle.SEM_STEP)
+    assert np.array_equal(obs[:T].cpu().numpy(), o_ref)  # trig-free: bit-exact
+    # closed form: x_{k+1} = Ad x_k + Bd u_k
+    d, k, m, tau = 1.0, 100.0, 1.0, spec["tau"]
+    M = np.array([[0, 1, 0], [-k / m, -d / m, 1 / m], [0, 0, 0]])
+    E = expm(M * tau)
+    Ad, Bd = E[:2, :2], E[:2, 2]
+    x = np.stack(st_small, axis=1)
+    u = (acts_small[..., 0] + 1) / 2 * 40 - 20
+    exact = [x]
+    for j in range(K):
+        x = x @ Ad.T + u[:, j:j + 1] * Bd[None, :]
+        exact.append(x)
+    exact = np.stack(exact, axis=1)
+    got = np.stack([states.physical_state.deflection[:T].cpu().numpy(), states.physical_state.velocity[:T].cpu().numpy()], axis=-1)
+    assert np.abs(got - exact).max() < 1e-11
