@@ -62,11 +62,15 @@ def build_env(args, device, rank):
     elif reg == "PENDULUM":
         ps.theta, ps.omega = u(-np.pi, np.pi), u(-1.0, 1.0)
     g.manual_seed(1237 + rank)
-    actions = env.new_actions_buffer(Kc) if args.action_layout == "lane_major" else torch.empty(
-        (B, Kc, env.action_dim), dtype=dtype, device=device)
-    flat = torch.rand(actions.numel(), generator=g, dtype=dtype, device=device) * 2 - 1
-    actions.copy_(flat.view(Kc, env.action_dim, B).permute(2, 0, 1))
-    del flat
+    if args.action_layout == "tiled":
+        actions = env.new_actions_buffer(Kc, layout="tiled")
+        actions.uniform_(-1, 1, generator=g)
+    else:
+        actions = env.new_actions_buffer(Kc) if args.action_layout == "lane_major" else torch.empty(
+            (B, Kc, env.action_dim), dtype=dtype, device=device)
+        flat = torch.rand(actions.numel(), generator=g, dtype=dtype, device=device) * 2 - 1
+        actions.copy_(flat.view(Kc, env.action_dim, B).permute(2, 0, 1))
+        del flat
     env.traj_layout = args.traj_layout
     return env, state, actions, B, Kc, reg, solver, dtype
 
@@ -137,8 +141,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="envs per GPU (default: the workload's 2^n)")
     ap.add_argument("--chunk", type=int, default=0, help="solver steps per launch")
     ap.add_argument("--semantics", default="ahead", choices=["ahead", "step"])
-    ap.add_argument("--traj-layout", default="lane_major", choices=["lane_major", "env_major"])
-    ap.add_argument("--action-layout", default="lane_major", choices=["lane_major", "env_major"])
+    ap.add_argument("--traj-layout", default="lane_major", choices=["lane_major", "env_major", "tiled"])
+    ap.add_argument("--action-layout", default="lane_major", choices=["lane_major", "env_major", "tiled"])
     ap.add_argument("--gather", default="final", choices=["final", "none"])
     ap.add_argument("--vec", type=int, default=0, help="envs per lane (0 auto)")
     ap.add_argument("--lds-pad", type=int, default=0, help="dynamic LDS bytes per workgroup (occupancy cap experiment)")
@@ -169,7 +173,12 @@ def main():
         _native.set_tuning(0, args.vec)
     if args.lds_pad:
         _native.set_tuning(1, args.lds_pad)
-    gatherer = ObservationGatherer(B * world) if (world > 1 and args.gather == "final") else None
+    use_gather = args.gather == "final" and (world > 1 or os.environ.get("EXCENV_BENCH_FORCE_GATHER") == "1")
+    if use_gather and not dist.is_initialized():  # 1-rank rehearsal of the collective path
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    gatherer = ObservationGatherer(B * world) if use_gather else None
     gathered = None
 
     step_actions = [actions[:, k, :].contiguous() for k in range(min(Kc, 8))] if args.path == "step" else None
@@ -184,7 +193,8 @@ def main():
         obs, states, last = env.vmap_sim_ahead(st, actions, env.tau, env.tau)
         if gatherer is not None:
             gatherer.wait()  # previous chunk's gather must have drained before its buffer is reused
-            gathered = gatherer.start(obs[:, -1, :], gathered)
+            final = obs[:, -1, :] if obs.ndim == 3 else obs[:, :, -1, :].reshape(B, -1)
+            gathered = gatherer.start(final, gathered)
         return last
 
     for _ in range(args.warmup):
@@ -271,7 +281,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, reg, solver, dtype, env.tau, Kc)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -112,8 +112,8 @@ int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
   if (int rc = check_common("excenv_sim_ahead", env, solver, dtype, B)) return rc;
   if (K < 0 || substeps < 1) { set_error("excenv_sim_ahead: bad K=%lld or substeps=%d", (long long)K, substeps); return EXCENV_EINVAL; }
   if (semantics != EXCENV_SEM_STEP && semantics != EXCENV_SEM_AHEAD) { set_error("excenv_sim_ahead: bad semantics %d", semantics); return EXCENV_EINVAL; }
-  if ((action_layout != EXCENV_LAYOUT_ENV_MAJOR && action_layout != EXCENV_LAYOUT_LANE_MAJOR) ||
-      (traj_layout != EXCENV_LAYOUT_ENV_MAJOR && traj_layout != EXCENV_LAYOUT_LANE_MAJOR)) {
+  if (action_layout < EXCENV_LAYOUT_ENV_MAJOR || action_layout > EXCENV_LAYOUT_TILED ||
+      traj_layout < EXCENV_LAYOUT_ENV_MAJOR || traj_layout > EXCENV_LAYOUT_TILED) {
     set_error("excenv_sim_ahead: bad layout id");
     return EXCENV_EINVAL;
   }

@@ -43,10 +43,11 @@ template <typename T, class M> struct SimArgs {
   T* last_state[M::S];
   const T* actions;
   int64_t a_sb, a_sk, a_sc;  // element strides of (env, action step, component)
+  int64_t a_wg;              // element offset between consecutive workgroups' first envs
   T* obs;
-  int64_t o_sb, o_sk, o_sc;
+  int64_t o_sb, o_sk, o_sc, o_wg;
   T* straj[M::S];  // straj[0] == nullptr: no state trajectory
-  int64_t s_sb, s_sk;
+  int64_t s_sb, s_sk, s_wg;
   int32_t control_idx[EXCENV_MAX_CONTROL];
   const T* reference[EXCENV_MAX_CONTROL];
   T dt, env_tau, adv_coef;
@@ -115,7 +116,7 @@ template <typename T, int V> __device__ __forceinline__ void store_v(T* p, const
 template <typename T, int V> __device__ __forceinline__ void store_stream(T* p, const T (&in)[V]) {
 #if EXCENV_NT_STORES
   if constexpr (V == 1) {
-    __builtin_nontemporal_store(in[0], p);
+    *p = in[0];  // V == 1 also serves the env-major layout, whose scattered words must merge in L2: no nt
   } else {
     typedef T NVT __attribute__((ext_vector_type(V)));  // the builtin wants a native clang vector
     NVT v;
@@ -224,9 +225,9 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
 
   const int64_t N = ka.K * ka.substeps;
   // V > 1 implies env stride 1; for V == 1 the host has checked that 256 * stride * sizeof(T) < 2^31
-  const T* a_blk = ka.actions + blk0 * ((V == 1) ? ka.a_sb : 1);
-  T* o_blk = ka.obs + blk0 * ((V == 1) ? ka.o_sb : 1);
-  const int64_t s_blk = blk0 * ((V == 1) ? ka.s_sb : 1);
+  const T* a_blk = ka.actions + (int64_t)blockIdx.x * ka.a_wg;
+  T* o_blk = ka.obs + (int64_t)blockIdx.x * ka.o_wg;
+  const int64_t s_blk = (int64_t)blockIdx.x * ka.s_wg;
   const unsigned a_lane = (V == 1) ? threadIdx.x * (unsigned)ka.a_sb : lane_env;
   const unsigned o_lane = (V == 1) ? threadIdx.x * (unsigned)ka.o_sb : lane_env;
   const unsigned s_lane = (V == 1) ? threadIdx.x * (unsigned)ka.s_sb : lane_env;

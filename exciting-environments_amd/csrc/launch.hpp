@@ -182,14 +182,24 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   }
   ka.actions = (const T*)sc.actions;
   ka.obs = (T*)sc.obs_traj;
+  constexpr int64_t TILE = EXCENV_TILE;  // envs per tile of the tiled layout (== one workgroup at V = TILE/BLOCK)
   if (sc.action_layout == EXCENV_LAYOUT_ENV_MAJOR) { ka.a_sb = sc.K * M::A; ka.a_sk = M::A; ka.a_sc = 1; }
+  else if (sc.action_layout == EXCENV_LAYOUT_TILED) { ka.a_sb = 1; ka.a_sk = (int64_t)M::A * TILE; ka.a_sc = TILE; }
   else { ka.a_sb = 1; ka.a_sk = (int64_t)M::A * sc.B; ka.a_sc = sc.B; }
   if (sc.traj_layout == EXCENV_LAYOUT_ENV_MAJOR) {
     ka.o_sb = (N + 1) * OW; ka.o_sk = OW; ka.o_sc = 1;
     ka.s_sb = N + 1; ka.s_sk = 1;
+  } else if (sc.traj_layout == EXCENV_LAYOUT_TILED) {
+    ka.o_sb = 1; ka.o_sk = OW * TILE; ka.o_sc = TILE;
+    ka.s_sb = 1; ka.s_sk = TILE;
   } else {
     ka.o_sb = 1; ka.o_sk = OW * sc.B; ka.o_sc = sc.B;
     ka.s_sb = 1; ka.s_sk = sc.B;
+  }
+  const bool tiled_a = sc.action_layout == EXCENV_LAYOUT_TILED, tiled_t = sc.traj_layout == EXCENV_LAYOUT_TILED;
+  if ((tiled_a || tiled_t) && (sc.B % TILE) != 0) {
+    set_error("excenv_sim_ahead: the tiled layout needs batch_size %% %lld == 0", (long long)TILE);
+    return EXCENV_EINVAL;
   }
   for (int j = 0; j < ka.n_control; ++j) {
     ka.control_idx[j] = sc.control->control_idx[j];
@@ -209,7 +219,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     }
   }
 
-  vec_ok &= (sc.action_layout == EXCENV_LAYOUT_LANE_MAJOR) && (sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR);
+  vec_ok &= (sc.action_layout != EXCENV_LAYOUT_ENV_MAJOR) && (sc.traj_layout != EXCENV_LAYOUT_ENV_MAJOR);
   vec_ok &= aligned16(ka.actions) && aligned16(ka.obs);
   constexpr int VMAX = 16 / (int)sizeof(T);
   int V = 1;
@@ -218,6 +228,29 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     if (want > VMAX) want = VMAX;
     while (want > 1 && (sc.B % want) != 0) want >>= 1;
     V = want;
+  }
+  if (tiled_a || tiled_t) {  // a workgroup must not straddle tiles
+    constexpr int VT = (int)(TILE / BLOCK);
+    if (VT > VMAX || batched || !vec_ok) {
+      if (TILE % BLOCK != 0) { set_error("tiled layout: TILE %% BLOCK != 0"); return EXCENV_EINVAL; }
+      V = 1;
+    } else {
+      V = VT;
+    }
+  }
+  {  // element offset of workgroup w's first env in each stream
+    const int64_t wg_envs = (int64_t)BLOCK * V;
+    auto wg_off = [&](int layout, int64_t sb, int64_t per_tile) -> int64_t {
+      if (layout == EXCENV_LAYOUT_TILED) return (wg_envs == TILE) ? per_tile : -1;
+      return wg_envs * sb;
+    };
+    ka.a_wg = wg_off(sc.action_layout, ka.a_sb, sc.K * M::A * TILE);
+    ka.o_wg = wg_off(sc.traj_layout, ka.o_sb, (N + 1) * OW * TILE);
+    ka.s_wg = wg_off(sc.traj_layout, ka.s_sb, (N + 1) * TILE);
+    if (ka.a_wg < 0 || ka.o_wg < 0 || ka.s_wg < 0) {
+      set_error("excenv_sim_ahead: tiled layout needs unbatched properties, 16-byte aligned buffers and the %d-byte dtype", 4);
+      return EXCENV_EUNSUPPORTED;
+    }
   }
 #define EXCENV_SIM_CASE(SOLV)                                                         \
   case SOLV:                                                                          \

@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 MAX_STATE, MAX_ACTION, MAX_STATIC, MAX_CONTROL = 8, 2, 9, 8
-LAYOUT_ENV_MAJOR, LAYOUT_LANE_MAJOR = 0, 1
+LAYOUT_ENV_MAJOR, LAYOUT_LANE_MAJOR, LAYOUT_TILED = 0, 1, 2
+TILE = 1024  # EXCENV_TILE
 SEM_STEP, SEM_AHEAD = 0, 1
 F32, F64 = 0, 1
 

@@ -380,7 +380,7 @@ class CoreEnvironment(ABC):
     def _run_sim_ahead(self, init_state, actions, env_properties, obs_stepsize, action_stepsize, B):
         S, A, OW = self.physical_state_dim, self.action_dim, self._obs_dim()
         actions = torch.as_tensor(actions)
-        K = actions.shape[1]
+        K = actions.shape[-2]
         sub = self._n_substeps(K, obs_stepsize, action_stepsize)
         N = K * sub
         props, keep = self._props_for(env_properties, B)
@@ -389,7 +389,12 @@ class CoreEnvironment(ABC):
 
         if actions.device != self.device or actions.dtype != self.dtype:
             actions = actions.to(device=self.device, dtype=self.dtype)
-        if K > 0 and B > 0 and tuple(actions.stride()) == (1, A * B, B):
+        T = _native.TILE
+        if actions.ndim == 4:  # [B/T, T, K, A] view over tiled [B/T, K, A, T] memory (new_actions_buffer(layout="tiled"))
+            assert tuple(actions.shape[:2]) == (B // T, T) and tuple(actions.stride()) == (K * A * T, 1, A * T, T), \
+                "4-D actions must come from new_actions_buffer(K, layout='tiled')"
+            a_layout = _native.LAYOUT_TILED
+        elif K > 0 and B > 0 and tuple(actions.stride()) == (1, A * B, B):
             a_layout = _native.LAYOUT_LANE_MAJOR  # a [K, A, B] buffer viewed as [B, K, A]
         else:
             actions = actions.contiguous()
@@ -401,13 +406,21 @@ class CoreEnvironment(ABC):
             t_layout = _native.LAYOUT_LANE_MAJOR
             observations = obs_buf.permute(2, 0, 1)
             st_views = [b.t() for b in st_buf]
+        elif self.traj_layout == "tiled":
+            # opt-in, NOT reference-shaped: tiles of T envs, each tile lane-major -> views [B/T, T, N+1, OW] / [B/T, T, N+1]
+            assert B % T == 0, f"traj_layout='tiled' needs batch_size % {T} == 0"
+            obs_buf = torch.empty((B // T, N + 1, OW, T), dtype=self.dtype, device=self.device)
+            st_buf = [torch.empty((B // T, N + 1, T), dtype=self.dtype, device=self.device) for _ in range(S)]
+            t_layout = _native.LAYOUT_TILED
+            observations = obs_buf.permute(0, 3, 1, 2)
+            st_views = [b.permute(0, 2, 1) for b in st_buf]
         elif self.traj_layout == "env_major":
             obs_buf = torch.empty((B, N + 1, OW), dtype=self.dtype, device=self.device)
             st_buf = [torch.empty((B, N + 1), dtype=self.dtype, device=self.device) for _ in range(S)]
             t_layout = _native.LAYOUT_ENV_MAJOR
             observations, st_views = obs_buf, st_buf
         else:
-            raise ValueError(f"traj_layout must be 'lane_major' or 'env_major', got {self.traj_layout!r}")
+            raise ValueError(f"traj_layout must be 'lane_major', 'env_major' or 'tiled', got {self.traj_layout!r}")
         last = [torch.empty(B, dtype=self.dtype, device=self.device) for _ in range(S)]
         sem = {"ahead": _native.SEM_AHEAD, "step": _native.SEM_STEP}[self.sim_ahead_semantics]
         _native.sim_ahead(self.ENV_ID, self._solver.id, self.dtype, B, K, sub, props, control, float(obs_stepsize),
@@ -454,9 +467,10 @@ class CoreEnvironment(ABC):
             obs_stepsize <= action_stepsize
         ), "The action stepsize should be greater or equal to the observation stepsize."
         actions = torch.as_tensor(actions)
-        assert actions.ndim == 3, "The actions need to have three dimensions: (batch_size, n_action_steps, action_dim)"
+        tiled_in = actions.ndim == 4 and actions.shape[0] * actions.shape[1] == self.batch_size
+        assert actions.ndim == 3 or tiled_in, "The actions need to have three dimensions: (batch_size, n_action_steps, action_dim)"
         assert (
-            actions.shape[0] == self.batch_size
+            tiled_in or actions.shape[0] == self.batch_size
         ), f"The first dimension does not correspond to the batch size which is {self.batch_size}, but {actions.shape[0]} is given"
         assert (
             actions.shape[-1] == self.action_dim
@@ -469,14 +483,24 @@ class CoreEnvironment(ABC):
         B = self.batch_size
         obs, st_views, last, N = self._run_sim_ahead(init_state, actions, self.env_properties, obs_stepsize,
                                                      action_stepsize, B)
-        states = self._traj_state(init_state, st_views, (B,), N)
+        if self.traj_layout == "tiled":
+            states = self.State(physical_state=self.PhysicalState(**dict(zip(self.STATE_FIELDS, st_views))),
+                                PRNGKey=None, additions=None, reference=None)
+        else:
+            states = self._traj_state(init_state, st_views, (B,), N)
         last_state = replace(init_state, physical_state=self.PhysicalState(**dict(zip(self.STATE_FIELDS, last))),
                              additions=self._additions((B,), True))
         return obs, states, last_state
 
-    def new_actions_buffer(self, n_action_steps: int):
+    def new_actions_buffer(self, n_action_steps: int, layout: str = "lane_major"):
         """A (batch_size, n_action_steps, action_dim) tensor whose memory is lane-major ([K, A, B]); filling this
-        and passing it to vmap_sim_ahead lets the kernel read actions fully coalesced with no transposition."""
+        and passing it to vmap_sim_ahead lets the kernel read actions fully coalesced with no transposition.
+        layout="tiled": a (B/T, T, K, A) view over [B/T, K, A, T] memory (opt-in tiled layout, T = 1024)."""
+        if layout == "tiled":
+            T = _native.TILE
+            assert self.batch_size % T == 0
+            buf = torch.empty((self.batch_size // T, n_action_steps, self.action_dim, T), dtype=self.dtype, device=self.device)
+            return buf.permute(0, 3, 1, 2)
         buf = torch.empty((n_action_steps, self.action_dim, self.batch_size), dtype=self.dtype, device=self.device)
         return buf.permute(2, 0, 1)
 

@@ -19,6 +19,9 @@
  *                              state leaves [B,K+1] (core_env.py:571-616).
  *   EXCENV_LAYOUT_LANE_MAJOR : element (b,k,c) at ((k*C)+c)*B + b  — one lane per env,
  *                              lane-adjacent envs address-adjacent (fully coalesced).
+ *   EXCENV_LAYOUT_TILED      : lane-major inside tiles of EXCENV_TILE envs: element (b,k,c) at
+ *                              (b/TILE)*K*C*TILE + ((k*C)+c)*TILE + b%TILE — every workgroup owns one tile and
+ *                              writes ONE sequential stream (fp32, batch_size % TILE == 0, unbatched properties).
  */
 #ifndef EXCENV_H
 #define EXCENV_H
@@ -49,7 +52,8 @@ typedef enum { EXCENV_EULER = 0, EXCENV_RK4 = 1, EXCENV_TSIT5 = 2, EXCENV_NUM_SO
 
 typedef enum { EXCENV_F32 = 0, EXCENV_F64 = 1 } excenv_dtype_t;
 
-typedef enum { EXCENV_LAYOUT_ENV_MAJOR = 0, EXCENV_LAYOUT_LANE_MAJOR = 1 } excenv_layout_t;
+typedef enum { EXCENV_LAYOUT_ENV_MAJOR = 0, EXCENV_LAYOUT_LANE_MAJOR = 1, EXCENV_LAYOUT_TILED = 2 } excenv_layout_t;
+#define EXCENV_TILE 1024 /* environments per tile of EXCENV_LAYOUT_TILED */
 
 /* Trajectory semantics of excenv_sim_ahead.
  *   EXCENV_SEM_STEP  : the K steps are exactly K applications of excenv_step (post-processing —
