@@ -72,6 +72,7 @@ def build_env(args, device, rank):
         actions.copy_(flat.view(Kc, env.action_dim, B).permute(2, 0, 1))
         del flat
     env.traj_layout = args.traj_layout
+    env.env_major_workspace = not getattr(args, "no_workspace", False)
     return env, state, actions, B, Kc, reg, solver, dtype
 
 
@@ -148,6 +149,7 @@ def main():
     ap.add_argument("--lds-pad", type=int, default=0, help="dynamic LDS bytes per workgroup (occupancy cap experiment)")
     ap.add_argument("--path", default="sim_ahead", choices=["sim_ahead", "step"],
                     help="sim_ahead: one persistent launch per bench step (headline); step: one vmap_step launch per bench step")
+    ap.add_argument("--no-workspace", action="store_true", help="env-major buffers: use the generic-stride kernel path")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -16,6 +16,8 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int launch_transpose(int dtype, int64_t M, int64_t N, const void* in, void* out, hipStream_t stream);
+
 EnvVTable vtable_pendulum();
 EnvVTable vtable_msd();
 EnvVTable vtable_cartpole();
@@ -100,15 +102,39 @@ int excenv_step(int env, int solver, int dtype, int64_t B, const excenv_props_t*
   if (int rc = check_common("excenv_step", env, solver, dtype, B)) return rc;
   if (!props || !state_in || !action || !state_out || !obs) { set_error("excenv_step: NULL argument"); return EXCENV_ENULL; }
   if (int rc = check_control("excenv_step", env, control)) return rc;
-  StepCall sc{solver, dtype, B, props, control, tau, state_in, action, state_out, obs, (hipStream_t)stream};
+  StepCall sc{g_vec_pref, solver, dtype, B, props, control, tau, state_in, action, state_out, obs, (hipStream_t)stream};
   return table(env)->step(sc);
 }
 
-int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32_t substeps,
-                     const excenv_props_t* props, const excenv_control_t* control, double obs_stepsize,
-                     double env_tau, const void* const* state_in, const void* actions, int action_layout,
-                     void* obs_traj, void* const* state_traj, int traj_layout, void* const* last_state,
-                     int semantics, void* stream) {
+static inline int64_t align_up(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+int64_t excenv_sim_ahead_workspace_bytes(int env, int dtype, int64_t B, int64_t K, int32_t substeps, int32_t n_control,
+                                         int action_layout, int traj_layout, int with_state_traj) {
+  const EnvVTable* t = table(env);
+  if (!t || B < 0 || K < 0 || substeps < 1 || n_control < 0) return -1;
+  const int64_t w = dtype == EXCENV_F64 ? 8 : 4, N = K * substeps;
+  int64_t bytes = 0;
+  if (action_layout == EXCENV_LAYOUT_ENV_MAJOR) bytes += align_up(w * K * t->A * B);
+  if (traj_layout == EXCENV_LAYOUT_ENV_MAJOR) {
+    bytes += align_up(w * (N + 1) * (t->O + n_control) * B);
+    if (with_state_traj) bytes += (int64_t)t->S * align_up(w * (N + 1) * B);
+  }
+  return bytes;
+}
+
+int excenv_transpose(int dtype, int64_t M, int64_t N, const void* in, void* out, void* stream) {
+  if ((dtype != EXCENV_F32 && dtype != EXCENV_F64) || M < 0 || N < 0) { set_error("excenv_transpose: bad argument"); return EXCENV_EINVAL; }
+  if ((!in || !out) && M * N > 0) { set_error("excenv_transpose: NULL argument"); return EXCENV_ENULL; }
+  int rc = launch_transpose(dtype, M, N, in, out, (hipStream_t)stream);
+  if (rc) set_error("excenv_transpose: launch failed");
+  return rc;
+}
+
+int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, int32_t substeps,
+                        const excenv_props_t* props, const excenv_control_t* control, double obs_stepsize,
+                        double env_tau, const void* const* state_in, const void* actions, int action_layout,
+                        void* obs_traj, void* const* state_traj, int traj_layout, void* const* last_state,
+                        int semantics, void* workspace, int64_t workspace_bytes, void* stream) {
   if (int rc = check_common("excenv_sim_ahead", env, solver, dtype, B)) return rc;
   if (K < 0 || substeps < 1) { set_error("excenv_sim_ahead: bad K=%lld or substeps=%d", (long long)K, substeps); return EXCENV_EINVAL; }
   if (semantics != EXCENV_SEM_STEP && semantics != EXCENV_SEM_AHEAD) { set_error("excenv_sim_ahead: bad semantics %d", semantics); return EXCENV_EINVAL; }
@@ -119,9 +145,60 @@ int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
   }
   if (!props || !state_in || (!actions && K > 0) || !obs_traj || !last_state) { set_error("excenv_sim_ahead: NULL argument"); return EXCENV_ENULL; }
   if (int rc = check_control("excenv_sim_ahead", env, control)) return rc;
-  SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, actions, action_layout,
-             obs_traj, state_traj, traj_layout, last_state, semantics, g_vec_pref, g_lds_pad, (hipStream_t)stream};
-  return table(env)->sim(sc);
+  const EnvVTable* t = table(env);
+  const int nc = control ? control->n_control : 0;
+  const int64_t need = excenv_sim_ahead_workspace_bytes(env, dtype, B, K, substeps, nc, action_layout, traj_layout,
+                                                        state_traj != nullptr);
+  const bool via_ws = workspace && need > 0 && workspace_bytes >= need && B > 0 &&
+                      (action_layout == EXCENV_LAYOUT_ENV_MAJOR || traj_layout == EXCENV_LAYOUT_ENV_MAJOR);
+  if (!via_ws) {
+    SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, actions, action_layout,
+               obs_traj, state_traj, traj_layout, last_state, semantics, g_vec_pref, g_lds_pad, (hipStream_t)stream};
+    return t->sim(sc);
+  }
+  // env-major buffers + workspace: transpose in, run the coalesced lane-major kernel, transpose out
+  const int64_t w = dtype == EXCENV_F64 ? 8 : 4, N = K * substeps, OW = t->O + nc;
+  char* ws = (char*)workspace;
+  const void* k_actions = actions;
+  int k_alayout = action_layout, k_tlayout = traj_layout;
+  void* k_obs = obs_traj;
+  void* k_straj[EXCENV_MAX_STATE] = {nullptr};
+  void* const* k_straj_p = state_traj;
+  hipStream_t st = (hipStream_t)stream;
+  if (action_layout == EXCENV_LAYOUT_ENV_MAJOR) {
+    if (int rc = launch_transpose(dtype, B, K * t->A, actions, ws, st)) { set_error("excenv_sim_ahead: action transpose failed"); return rc; }
+    k_actions = ws;
+    k_alayout = EXCENV_LAYOUT_LANE_MAJOR;
+    ws += align_up(w * K * t->A * B);
+  }
+  if (traj_layout == EXCENV_LAYOUT_ENV_MAJOR) {
+    k_obs = ws;
+    ws += align_up(w * (N + 1) * OW * B);
+    if (state_traj) {
+      for (int j = 0; j < t->S; ++j) { k_straj[j] = ws; ws += align_up(w * (N + 1) * B); }
+      k_straj_p = k_straj;
+    }
+    k_tlayout = EXCENV_LAYOUT_LANE_MAJOR;
+  }
+  SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, k_actions, k_alayout,
+             k_obs, k_straj_p, k_tlayout, last_state, semantics, g_vec_pref, g_lds_pad, st};
+  if (int rc = t->sim(sc)) return rc;
+  if (traj_layout == EXCENV_LAYOUT_ENV_MAJOR) {
+    if (int rc = launch_transpose(dtype, (N + 1) * OW, B, k_obs, obs_traj, st)) { set_error("excenv_sim_ahead: obs transpose failed"); return rc; }
+    if (state_traj)
+      for (int j = 0; j < t->S; ++j)
+        if (int rc = launch_transpose(dtype, N + 1, B, k_straj[j], state_traj[j], st)) { set_error("excenv_sim_ahead: state transpose failed"); return rc; }
+  }
+  return EXCENV_OK;
+}
+
+int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32_t substeps,
+                     const excenv_props_t* props, const excenv_control_t* control, double obs_stepsize,
+                     double env_tau, const void* const* state_in, const void* actions, int action_layout,
+                     void* obs_traj, void* const* state_traj, int traj_layout, void* const* last_state,
+                     int semantics, void* stream) {
+  return excenv_sim_ahead_ws(env, solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, actions,
+                             action_layout, obs_traj, state_traj, traj_layout, last_state, semantics, nullptr, 0, stream);
 }
 
 int excenv_probe_math(int which, int dtype, int64_t n, const void* in, void* out, void* stream) {

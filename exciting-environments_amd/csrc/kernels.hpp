@@ -154,24 +154,47 @@ template <typename T, int N> __device__ __forceinline__ void load_row(const T* s
 }
 
 // ---- vmap_step: one fused launch (reference core_env.py:533-569) ---------------------------
-template <class M, typename T, int SOLVER, bool BATCHED>
+// V adjacent envs per lane (V > 1 only without batched properties / control columns): [B] state arrays move as
+// 16-byte vectors, the row-major action / obs rows of the V envs are one contiguous run of V*A / V*O words.
+template <class M, typename T, int SOLVER, bool BATCHED, int V>
 __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  static_assert(!(BATCHED && V > 1), "vectorised lanes share one uniform property set");
+  const int64_t blk0 = (int64_t)blockIdx.x * (BLOCK * V);
+  const unsigned lane_env = threadIdx.x * V;
+  const int64_t i = blk0 + lane_env;
   if (i >= ka.B) return;
   Ctx<T, M> c;
   load_ctx<BATCHED>(c, ka.kp, i, ka.dt, ka.env_tau, ka.adv_coef);
-  T st[S], a[A], ob[O];
+  T st[V][S], a[V * A], ob[V * O];
 #pragma unroll
-  for (int j = 0; j < S; ++j) st[j] = ka.state_in[j][i];
-  load_row<T, A>(ka.action + i * A, a);
-  env_step<M, SOLVER>(st, a, c);
-  M::observe(st, c, ob);
+  for (int j = 0; j < S; ++j) {
+    T tmp[V];
+    load_v<T, V>(ka.state_in[j] + blk0 + lane_env, tmp);
 #pragma unroll
-  for (int j = 0; j < S; ++j) ka.state_out[j][i] = st[j];
+    for (int v = 0; v < V; ++v) st[v][j] = tmp[v];
+  }
+  load_row<T, V * A>(ka.action + blk0 * A + lane_env * A, a);
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    T av[A], ov[O];
+#pragma unroll
+    for (int q = 0; q < A; ++q) av[q] = a[v * A + q];
+    env_step<M, SOLVER>(st[v], av, c);
+    M::observe(st[v], c, ov);
+#pragma unroll
+    for (int q = 0; q < O; ++q) ob[v * O + q] = ov[q];
+  }
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    T tmp[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) tmp[v] = st[v][j];
+    store_v<T, V>(ka.state_out[j] + blk0 + lane_env, tmp);
+  }
   if (ka.n_control == 0) {
-    store_row<T, O>(ka.obs + i * O, ob);
-  } else {
+    store_row<T, V * O>(ka.obs + blk0 * O + lane_env * O, ob);
+  } else {  // V == 1 here (host)
     T* row = ka.obs + i * (O + ka.n_control);
 #pragma unroll
     for (int j = 0; j < O; ++j) row[j] = ob[j];

@@ -11,6 +11,7 @@ namespace excenv {
 void set_error(const char* fmt, ...);
 
 struct StepCall {
+  int vec_pref;  // 0 auto, else forced envs per lane
   int solver, dtype;
   int64_t B;
   const excenv_props_t* props;
@@ -124,11 +125,25 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
     return EXCENV_EINVAL;
   }
   if (sc.B == 0) return EXCENV_OK;
-  const dim3 grid((unsigned)((sc.B + BLOCK - 1) / BLOCK)), block(BLOCK);
-#define EXCENV_STEP_CASE(SOLV)                                                                         \
-  case SOLV:                                                                                           \
-    if (batched) hipLaunchKernelGGL((step_kernel<M, T, SOLV, true>), grid, block, 0, sc.stream, ka);   \
-    else hipLaunchKernelGGL((step_kernel<M, T, SOLV, false>), grid, block, 0, sc.stream, ka);          \
+  constexpr int VMAX = 16 / (int)sizeof(T);
+  int V = 1;
+  if (!batched && ka.n_control == 0) {
+    bool ok = true;
+    for (int j = 0; j < M::S; ++j) ok &= aligned16(ka.state_in[j]) && aligned16(ka.state_out[j]);
+    int want = sc.vec_pref > 0 ? sc.vec_pref : 1;  // measured: one env per lane is fastest on this path
+    if (want > VMAX) want = VMAX;
+    while (want > 1 && (sc.B % want) != 0) want >>= 1;
+    if (ok) V = want;
+  }
+  const int64_t lanes = sc.B / V;
+  const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
+#define EXCENV_STEP_LAUNCH(SOLV, BAT, VV) hipLaunchKernelGGL((step_kernel<M, T, SOLV, BAT, VV>), grid, block, 0, sc.stream, ka)
+#define EXCENV_STEP_CASE(SOLV)                                             \
+  case SOLV:                                                               \
+    if (batched) EXCENV_STEP_LAUNCH(SOLV, true, 1);                        \
+    else if (V == 2) EXCENV_STEP_LAUNCH(SOLV, false, 2);                   \
+    else if (V == 1) EXCENV_STEP_LAUNCH(SOLV, false, 1);                   \
+    else { if constexpr (sizeof(T) == 4) EXCENV_STEP_LAUNCH(SOLV, false, 4); } \
     break;
   switch (sc.solver) {
     EXCENV_STEP_CASE(EXCENV_EULER)
@@ -137,6 +152,7 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
     default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
   }
 #undef EXCENV_STEP_CASE
+#undef EXCENV_STEP_LAUNCH
   return check_launch("excenv_step");
 }
 

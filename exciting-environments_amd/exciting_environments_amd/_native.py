@@ -66,7 +66,9 @@ def lib():
         l.excenv_abi_version.restype = ctypes.c_int
         l.excenv_step_bytes.restype = ctypes.c_int64
         l.excenv_sim_ahead_bytes.restype = ctypes.c_int64
-        for fn in ("excenv_step", "excenv_sim_ahead", "excenv_env_dims", "excenv_probe_math", "excenv_set_tuning"):
+        l.excenv_sim_ahead_workspace_bytes.restype = ctypes.c_int64
+        for fn in ("excenv_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
+                   "excenv_probe_math", "excenv_set_tuning"):
             getattr(l, fn).restype = ctypes.c_int
         if l.excenv_abi_version() != 1:
             raise ImportError("libexcenv_hip.so: ABI version mismatch")
@@ -146,20 +148,44 @@ def step(env_id, solver_id, dtype, B, props: Props, control: Optional[Control], 
 def sim_ahead(env_id, solver_id, dtype, B, K, substeps, props: Props, control: Optional[Control],
               obs_stepsize: float, env_tau: float, state_in: Sequence[torch.Tensor], actions: torch.Tensor,
               action_layout: int, obs_traj: torch.Tensor, state_traj: Optional[Sequence[torch.Tensor]],
-              traj_layout: int, last_state: Sequence[torch.Tensor], semantics: int):
+              traj_layout: int, last_state: Sequence[torch.Tensor], semantics: int,
+              workspace: Optional[torch.Tensor] = None):
     _require_device(obs_traj, "vmap_sim_ahead")
     with torch.cuda.device(obs_traj.device):
         stream = torch.cuda.current_stream(obs_traj.device).cuda_stream
-        rc = lib().excenv_sim_ahead(
+        rc = lib().excenv_sim_ahead_ws(
             ctypes.c_int(env_id), ctypes.c_int(solver_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B),
             ctypes.c_int64(K), ctypes.c_int32(substeps), ctypes.byref(props),
             ctypes.byref(control) if control is not None else None, ctypes.c_double(obs_stepsize),
             ctypes.c_double(env_tau), _ptrs(state_in), ctypes.c_void_p(actions.data_ptr() if K > 0 else None),
             ctypes.c_int(action_layout), ctypes.c_void_p(obs_traj.data_ptr()),
             _ptrs(state_traj) if state_traj is not None else None, ctypes.c_int(traj_layout), _ptrs(last_state),
-            ctypes.c_int(semantics), ctypes.c_void_p(stream),
+            ctypes.c_int(semantics), ctypes.c_void_p(workspace.data_ptr() if workspace is not None else None),
+            ctypes.c_int64(workspace.numel() * workspace.element_size() if workspace is not None else 0),
+            ctypes.c_void_p(stream),
         )
     _check(rc, "excenv_sim_ahead")
+
+
+def sim_ahead_workspace_bytes(env_id, dtype, B, K, substeps, n_control, action_layout, traj_layout,
+                              with_state_traj=True) -> int:
+    return int(lib().excenv_sim_ahead_workspace_bytes(
+        ctypes.c_int(env_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B), ctypes.c_int64(K),
+        ctypes.c_int32(substeps), ctypes.c_int32(n_control), ctypes.c_int(action_layout), ctypes.c_int(traj_layout),
+        ctypes.c_int(int(with_state_traj))))
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    """out[n][m] = in[m][n] for a contiguous 2-D device tensor (the library's LDS-tiled conversion kernel)."""
+    _require_device(x, "transpose")
+    assert x.ndim == 2 and x.is_contiguous()
+    out = torch.empty((x.shape[1], x.shape[0]), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = lib().excenv_transpose(ctypes.c_int(dtype_id(x.dtype)), ctypes.c_int64(x.shape[0]), ctypes.c_int64(x.shape[1]),
+                                    ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream))
+    _check(rc, "excenv_transpose")
+    return out
 
 
 def probe_math(which: int, x: torch.Tensor) -> torch.Tensor:

@@ -95,6 +95,8 @@ class CoreEnvironment(ABC):
         self.traj_layout = "lane_major"
         # "ahead": structure of the reference's _ode_solver_simulate_ahead; "step": K exact `step`s.
         self.sim_ahead_semantics = "ahead"
+        # env-major buffers: True = transpose through a scratch workspace (fast), False = generic-stride kernel path
+        self.env_major_workspace = True
         self._packed_props = None
 
     # ------------------------------------------------------------------ properties plumbing
@@ -423,8 +425,16 @@ class CoreEnvironment(ABC):
             raise ValueError(f"traj_layout must be 'lane_major', 'env_major' or 'tiled', got {self.traj_layout!r}")
         last = [torch.empty(B, dtype=self.dtype, device=self.device) for _ in range(S)]
         sem = {"ahead": _native.SEM_AHEAD, "step": _native.SEM_STEP}[self.sim_ahead_semantics]
+        workspace = None
+        if self.env_major_workspace and B > 0 and _native.LAYOUT_ENV_MAJOR in (a_layout, t_layout):
+            # env-major (row-major) buffers: let the library transpose through a scratch buffer instead of issuing
+            # scattered 4-byte accesses (excenv_sim_ahead_ws)
+            nbytes = _native.sim_ahead_workspace_bytes(self.ENV_ID, self.dtype, B, K, sub, len(self.control_state),
+                                                       a_layout, t_layout, True)
+            if nbytes > 0:
+                workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         _native.sim_ahead(self.ENV_ID, self._solver.id, self.dtype, B, K, sub, props, control, float(obs_stepsize),
-                          float(self.tau), st_in, actions, a_layout, obs_buf, st_buf, t_layout, last, sem)
+                          float(self.tau), st_in, actions, a_layout, obs_buf, st_buf, t_layout, last, sem, workspace)
         return observations, st_views, last, N
 
     def _traj_state(self, init_state, st_views, lead_shape, N):

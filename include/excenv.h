@@ -139,6 +139,21 @@ int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
                      void* obs_traj, void* const* state_traj, int traj_layout,
                      void* const* last_state, int semantics, void* stream);
 
+/* Same as excenv_sim_ahead, with a caller-provided device workspace. When a layout is EXCENV_LAYOUT_ENV_MAJOR
+ * (the reference's row-major arrays) and `workspace_bytes >= excenv_sim_ahead_workspace_bytes(...)`, the library
+ * transposes the actions into the workspace, runs the coalesced lane-major kernel there and transposes the
+ * trajectories back with an LDS-tiled kernel (3 launches + S small ones, all on `stream`); without a workspace the
+ * generic-stride path of the same kernel is used (one lane per env, scattered words). Results are bit-identical. */
+int64_t excenv_sim_ahead_workspace_bytes(int env, int dtype, int64_t B, int64_t K, int32_t substeps, int32_t n_control,
+                                         int action_layout, int traj_layout, int with_state_traj);
+int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, int32_t substeps,
+                        const excenv_props_t* props, const excenv_control_t* control, double obs_stepsize,
+                        double env_tau, const void* const* state_in, const void* actions, int action_layout,
+                        void* obs_traj, void* const* state_traj, int traj_layout, void* const* last_state,
+                        int semantics, void* workspace, int64_t workspace_bytes, void* stream);
+/* out[n][m] = in[m][n] for a row-major M x N matrix of the given dtype (the conversion kernel used above). */
+int excenv_transpose(int dtype, int64_t M, int64_t N, const void* in, void* out, void* stream);
+
 /* ---- tuning (no reference counterpart) -------------------------------------------------------
  * key 0: environments per lane for lane-major trajectories (0 = auto, 1/2/4 = forced). Process-wide.
  * key 1: dynamic LDS bytes requested per sim_ahead workgroup (the kernels use no LDS; this only caps the

@@ -155,8 +155,15 @@ def test_envs_per_lane_variants_are_bit_identical(env_name, vec):
     a_lane.copy_(torch.as_tensor(acts, device=env.device))
     a_env = torch.as_tensor(acts, device=env.device)
     env.traj_layout = "env_major"
+    env.env_major_workspace = False  # generic-stride kernel path
     ref_obs, ref_states, ref_last = env.vmap_sim_ahead(to_state(env, st), a_env, env.tau, env.tau)
     assert ref_obs.is_contiguous()
+    env.env_major_workspace = True  # transposing path through a workspace: same bits, contiguous row-major result
+    ws_obs, ws_states, ws_last = env.vmap_sim_ahead(to_state(env, st), a_env, env.tau, env.tau)
+    assert ws_obs.is_contiguous() and torch.equal(ws_obs, ref_obs)
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(ws_states.physical_state, n), getattr(ref_states.physical_state, n))
+        assert torch.equal(getattr(ws_last.physical_state, n), getattr(ref_last.physical_state, n))
     env.traj_layout = "lane_major"
     old = _native.set_tuning(0, vec)
     try:
@@ -290,6 +297,56 @@ def test_single_env_api_and_empty_trajectory():
     o0, s0, l0 = env4.vmap_sim_ahead(st4, torch.empty((4, 0, 1)), env4.tau, env4.tau)
     assert o0.shape == (4, 1, 2)
     assert torch.equal(l0.physical_state.omega, st4.physical_state.omega)
+
+
+@pytest.mark.parametrize("env_name", ["pmsm", "acrobot", "fluid_tank"])
+def test_step_kernel_envs_per_lane_variants_are_bit_identical(env_name):
+    from exciting_environments_amd import _native
+
+    B = 4096
+    env, props, keep, spec = make_env(env_name, B, torch.float32, "rk4")
+    st = random_state(env_name, B, np.float32, spec, seed=91)
+    act = torch.as_tensor(np.random.default_rng(92).uniform(-1, 1, (B, env.action_dim)).astype(np.float32), device=env.device)
+    outs = []
+    for vec in (1, 2, 4):
+        old = _native.set_tuning(0, vec)
+        try:
+            outs.append(env.vmap_step(to_state(env, st), act))
+        finally:
+            _native.set_tuning(0, old)
+    for obs, new in outs[1:]:
+        assert torch.equal(obs, outs[0][0])
+        for n in env.STATE_FIELDS:
+            assert torch.equal(getattr(new.physical_state, n), getattr(outs[0][1].physical_state, n))
+
+
+def test_tiled_layout_is_lane_major_per_tile():
+    """EXCENV_LAYOUT_TILED (opt-in): same bits as the lane-major run, tile by tile."""
+    B, K = 4096, 21
+    env, props, keep, spec = make_env("pmsm", B, torch.float32)
+    st = random_state("pmsm", B, np.float32, spec, seed=95)
+    acts = torch.as_tensor(np.random.default_rng(96).uniform(-1, 1, (B, K, 2)).astype(np.float32), device=env.device)
+    a_lane = env.new_actions_buffer(K)
+    a_lane.copy_(acts)
+    ref_obs, ref_states, ref_last = env.vmap_sim_ahead(to_state(env, st), a_lane, env.tau, env.tau)
+    a_tiled = env.new_actions_buffer(K, layout="tiled")
+    a_tiled.copy_(acts.view(B // 1024, 1024, K, 2))
+    env.traj_layout = "tiled"
+    obs, states, last = env.vmap_sim_ahead(to_state(env, st), a_tiled, env.tau, env.tau)
+    assert obs.shape == (B // 1024, 1024, K + 1, 8)
+    assert torch.equal(obs.reshape(B, K + 1, 8), ref_obs)
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(states.physical_state, n).reshape(B, K + 1), getattr(ref_states.physical_state, n))
+        assert torch.equal(getattr(last.physical_state, n), getattr(ref_last.physical_state, n))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (64, 64), (65, 63), (1000, 3), (3, 1000), (4097, 257)])
+def test_transpose_kernel(shape):
+    from exciting_environments_amd import _native
+
+    for dt in (torch.float32, torch.float64):
+        x = torch.randn(shape, dtype=dt, device="cuda")
+        assert torch.equal(_native.transpose(x), x.t().contiguous())
 
 
 # ------------------------------------------------------------------------------------------------ device math
