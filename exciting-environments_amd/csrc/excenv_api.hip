@@ -102,7 +102,29 @@ int excenv_step(int env, int solver, int dtype, int64_t B, const excenv_props_t*
   if (int rc = check_common("excenv_step", env, solver, dtype, B)) return rc;
   if (!props || !state_in || !action || !state_out || !obs) { set_error("excenv_step: NULL argument"); return EXCENV_ENULL; }
   if (int rc = check_control("excenv_step", env, control)) return rc;
-  StepCall sc{g_vec_pref, solver, dtype, B, props, control, tau, state_in, action, state_out, obs, (hipStream_t)stream};
+  StepCall sc{g_vec_pref, solver, dtype, B, props, control, tau, state_in, action, state_out, obs, nullptr, nullptr, nullptr,
+              (hipStream_t)stream};
+  return table(env)->step(sc);
+}
+
+int32_t excenv_truncated_width(int env, int32_t n_control) {
+  const EnvVTable* t = table(env);
+  if (!t || n_control < 0) return -1;
+  return (env == EXCENV_FLUID_TANK || env == EXCENV_PMSM) ? 1 : t->O + n_control;
+}
+
+int excenv_gym_step(int env, int solver, int dtype, int64_t B, const excenv_props_t* props,
+                    const excenv_control_t* control, double tau, const void* const* state_in, const void* action,
+                    void* const* state_out, void* obs, void* reward, uint8_t* terminated, uint8_t* truncated,
+                    void* stream) {
+  if (int rc = check_common("excenv_gym_step", env, solver, dtype, B)) return rc;
+  if (!props || !state_in || !action || !state_out || !obs || !reward || !terminated || !truncated) {
+    set_error("excenv_gym_step: NULL argument");
+    return EXCENV_ENULL;
+  }
+  if (int rc = check_control("excenv_gym_step", env, control)) return rc;
+  StepCall sc{1, solver, dtype, B, props, control, tau, state_in, action, state_out, obs, reward, terminated, truncated,
+              (hipStream_t)stream};
   return table(env)->step(sc);
 }
 

@@ -32,6 +32,10 @@ template <typename T, class M> struct StepArgs {
   int32_t control_idx[EXCENV_MAX_CONTROL];
   const T* reference[EXCENV_MAX_CONTROL];
   T dt, env_tau, adv_coef;
+  // optional gym outputs (all three or none): reward [B], terminated [B] (0/1 bytes), truncated [B][TW] (0/1 bytes)
+  T* reward;
+  uint8_t* terminated;
+  uint8_t* truncated;
 };
 
 template <typename T, class M> struct SimArgs {
@@ -208,6 +212,34 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
         hi = (f == q) ? c.smax[q] : hi;
       }
       row[O + j] = normalize(r, lo, hi);
+    }
+  }
+  if constexpr (V == 1) {
+    if (ka.reward != nullptr) {  // GymWrapper.gym_step (gym_wrapper.py:117-126), fused: no second pass over the state
+      T refs[EXCENV_MAX_CONTROL];
+      for (int j = 0; j < ka.n_control; ++j) refs[j] = ka.reference[j][i];
+      const T rew = env_reward<M, T>(st[0], c, ka.n_control, ka.control_idx, refs);
+      ka.reward[i] = rew;
+      if constexpr (M::ID == EXCENV_PMSM) {  // pmsm_env.py:972-983: |i_dq_norm| > 1, terminated == truncated
+        const T nd = normalize(st[0][3], c.smin[3], c.smax[3]), nq = normalize(st[0][4], c.smin[4], c.smax[4]);
+        const uint8_t t = xsqrt(nd * nd + nq * nq) > T(1);
+        ka.truncated[i] = t;
+        ka.terminated[i] = t;
+      } else if constexpr (M::ID == EXCENV_FLUID_TANK) {  // fluid_tank_env.py:325-333: constants
+        ka.truncated[i] = 0;
+        ka.terminated[i] = 0;
+      } else {  // truncated = |obs| > 1 over every observation column, terminated = (reward == 0)
+        const int OW = O + ka.n_control;
+        uint8_t* trow = ka.truncated + i * OW;
+#pragma unroll
+        for (int q = 0; q < O; ++q) trow[q] = xabs(ob[q]) > T(1);
+        for (int j = 0; j < ka.n_control; ++j) {
+          T x, lo, hi;
+          pick_field<M, T>(st[0], c, ka.control_idx[j], x, lo, hi);
+          trow[O + j] = xabs(normalize(refs[j], lo, hi)) > T(1);
+        }
+        ka.terminated[i] = rew == T(0);
+      }
     }
   }
 }

@@ -21,6 +21,9 @@ struct StepCall {
   const void* action;
   void* const* state_out;
   void* obs;
+  void* reward;       // optional gym outputs
+  void* terminated;
+  void* truncated;
   hipStream_t stream;
 };
 
@@ -120,6 +123,9 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
   ka.dt = (T)sc.tau;
   ka.env_tau = (T)sc.tau;
   ka.adv_coef = (T)coef;
+  ka.reward = (T*)sc.reward;
+  ka.terminated = (uint8_t*)sc.terminated;
+  ka.truncated = (uint8_t*)sc.truncated;
   if (!aligned16(ka.action) || !aligned16(ka.obs)) {
     set_error("excenv_step: action and obs must be 16-byte aligned");
     return EXCENV_EINVAL;
@@ -127,7 +133,7 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
   if (sc.B == 0) return EXCENV_OK;
   constexpr int VMAX = 16 / (int)sizeof(T);
   int V = 1;
-  if (!batched && ka.n_control == 0) {
+  if (!batched && ka.n_control == 0 && ka.reward == nullptr) {
     bool ok = true;
     for (int j = 0; j < M::S; ++j) ok &= aligned16(ka.state_in[j]) && aligned16(ka.state_out[j]);
     int want = sc.vec_pref > 0 ? sc.vec_pref : 1;  // measured: one env per lane is fastest on this path

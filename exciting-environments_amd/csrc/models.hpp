@@ -237,4 +237,86 @@ template <typename T> struct Pmsm {
   }
 };
 
+// ---- reward / truncated / terminated (reference generate_reward / generate_truncated / generate_terminated) -----
+// What GymWrapper.gym_step evaluates after every vmap_step (gym_wrapper.py:117-126). `ref[j]` is the physical
+// reference value of state field idx[j] (control_state order).
+template <class M> struct RttInfo {  // width of the truncated flag row
+  __host__ __device__ static constexpr bool one_flag() { return M::ID == EXCENV_FLUID_TANK || M::ID == EXCENV_PMSM; }
+};
+
+template <class M> __host__ __device__ constexpr bool is_angle_field(int f) {
+  return (M::ID == EXCENV_PENDULUM && f == 0) || (M::ID == EXCENV_CART_POLE && f == 2) ||
+         (M::ID == EXCENV_ACROBOT && (f == 0 || f == 1));
+}
+
+template <class M, typename T>
+__device__ __forceinline__ void pick_field(const T (&st)[M::S], const Ctx<T, M>& c, int f, T& x, T& lo, T& hi) {
+  x = st[0]; lo = c.smin[0]; hi = c.smax[0];
+#pragma unroll
+  for (int q = 1; q < M::S; ++q) {
+    x = (f == q) ? st[q] : x;
+    lo = (f == q) ? c.smin[q] : lo;
+    hi = (f == q) ? c.smax[q] : hi;
+  }
+}
+
+// e.g. pendulum_env.py:297-309, mass_spring_damper_env.py:296-302, pmsm_env.py:985-1037
+template <class M, typename T>
+__device__ __forceinline__ T env_reward(const T (&st)[M::S], const Ctx<T, M>& c, int n_control, const int* idx, const T* ref) {
+  T reward = T(0);
+  if constexpr (M::ID == EXCENV_PMSM) {
+    // control_state membership: "i_d" (3), "i_q" (4), "torque" (5)
+    T r_id = T(0), r_iq = T(0), r_tq = T(0);
+    bool has_id = false, has_iq = false, has_tq = false;
+    for (int j = 0; j < n_control; ++j) {
+      if (idx[j] == 3) { has_id = true; r_id = ref[j]; }
+      if (idx[j] == 4) { has_iq = true; r_iq = ref[j]; }
+      if (idx[j] == 5) { has_tq = true; r_tq = ref[j]; }
+    }
+    const T i_d = normalize(st[3], c.smin[3], c.smax[3]);
+    const T i_q = normalize(st[4], c.smin[4], c.smax[4]);
+    if (has_id && has_iq) {  // current_reward_func (pmsm_env.py:1010-1012), gamma = 0.85
+      const T dd = i_d - normalize(r_id, c.smin[3], c.smax[3]);
+      const T dq = i_q - normalize(r_iq, c.smin[4], c.smax[4]);
+      const T mse = T(0.5) * (dd * dd) + T(0.5) * (dq * dq);
+      reward = reward + T(-1) * (mse * T(1 - 0.85));
+    }
+    if (has_tq) {  // torque_reward_func(i_d, i_q, torque, torque_ref, 1, 0.85) (pmsm_env.py:1014-1037)
+      const T tq = normalize(st[5], c.smin[5], c.smax[5]);
+      const T tr = normalize(r_tq, c.smin[5], c.smax[5]);
+      const T i_s = xsqrt(i_d * i_d + i_q * i_q);
+      const T i_n = T(1), i_d_plus = T(0.2) * i_n, tol = T(0.01);
+      T rew = T(0);
+      rew = (i_s > T(1)) ? T(-1) * xabs(i_s) : rew;
+      rew = ((i_s < T(1)) && (i_s > i_n)) ? T(0.5) * (T(1) - (i_s - i_n) / (T(1) - i_n)) - T(1) : rew;
+      rew = ((i_s < i_n) && (i_d > i_d_plus)) ? T(-0.5) * ((i_d - i_d_plus) / (i_n - i_d_plus)) : rew;
+      const T ad = xabs(tq - tr);
+      rew = ((i_s < i_n) && (i_d < i_d_plus) && (ad > tol)) ? T(0.5) * (T(1) - xabs((tr - tq) / T(2))) : rew;
+      rew = ((i_s < i_n) && (i_d < i_d_plus) && (ad < tol)) ? T(1) - T(0.5) * i_s : rew;
+      reward = reward + rew * T(1 - 0.85);
+    }
+  } else {
+    for (int j = 0; j < n_control; ++j) {
+      const int f = idx[j];
+      T x, lo, hi;
+      pick_field<M, T>(st, c, f, x, lo, hi);
+      const T r = ref[j];
+      bool ang = false;
+#pragma unroll
+      for (int q = 0; q < M::S; ++q) ang = ang || (is_angle_field<M>(q) && f == q);
+      if (ang) {
+        T sx, cx, sr, cr;
+        sincos_t(x, sx, cx);
+        sincos_t(r, sr, cr);
+        const T ds = sx - sr, dc = cx - cr;
+        reward = reward + -(ds * ds + dc * dc);
+      } else {
+        const T d = normalize(x, lo, hi) - normalize(r, lo, hi);
+        reward = reward + -(d * d);
+      }
+    }
+  }
+  return reward;
+}
+
 }  // namespace excenv

@@ -12,12 +12,13 @@ Usage mirrors the reference package (README.md:15-33):
 from .core_env import CoreEnvironment
 from .envs import Acrobot, CartPole, FluidTank, MassSpringDamper, MotorVariant, Pendulum, PMSM
 from .registration import EnvironmentRegistry
+from .gym_wrapper import GymWrapper
 from .solvers import Euler, RK4, Tsit5
 from .utils import MinMaxNormalization, dump_sim_properties_to_json, load_sim_properties_from_json
 from . import tree, utils
 
 __all__ = [
     "CoreEnvironment", "Acrobot", "CartPole", "FluidTank", "MassSpringDamper", "Pendulum", "PMSM", "MotorVariant",
-    "EnvironmentRegistry", "Euler", "RK4", "Tsit5", "MinMaxNormalization", "dump_sim_properties_to_json",
+    "EnvironmentRegistry", "GymWrapper", "Euler", "RK4", "Tsit5", "MinMaxNormalization", "dump_sim_properties_to_json",
     "load_sim_properties_from_json", "tree", "utils",
 ]

@@ -67,7 +67,8 @@ def lib():
         l.excenv_step_bytes.restype = ctypes.c_int64
         l.excenv_sim_ahead_bytes.restype = ctypes.c_int64
         l.excenv_sim_ahead_workspace_bytes.restype = ctypes.c_int64
-        for fn in ("excenv_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
+        l.excenv_truncated_width.restype = ctypes.c_int32
+        for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
                    "excenv_probe_math", "excenv_set_tuning"):
             getattr(l, fn).restype = ctypes.c_int
         if l.excenv_abi_version() != 1:
@@ -143,6 +144,26 @@ def step(env_id, solver_id, dtype, B, props: Props, control: Optional[Control], 
             ctypes.c_void_p(stream),
         )
     _check(rc, "excenv_step")
+
+
+def truncated_width(env_id: int, n_control: int) -> int:
+    return int(lib().excenv_truncated_width(ctypes.c_int(env_id), ctypes.c_int32(n_control)))
+
+
+def gym_step(env_id, solver_id, dtype, B, props: Props, control: Optional[Control], tau: float,
+             state_in: Sequence[torch.Tensor], action: torch.Tensor, state_out: Sequence[torch.Tensor],
+             obs: torch.Tensor, reward: torch.Tensor, terminated: torch.Tensor, truncated: torch.Tensor):
+    _require_device(action, "gym_step")
+    with torch.cuda.device(action.device):
+        stream = torch.cuda.current_stream(action.device).cuda_stream
+        rc = lib().excenv_gym_step(
+            ctypes.c_int(env_id), ctypes.c_int(solver_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B),
+            ctypes.byref(props), ctypes.byref(control) if control is not None else None, ctypes.c_double(tau),
+            _ptrs(state_in), ctypes.c_void_p(action.data_ptr()), _ptrs(state_out), ctypes.c_void_p(obs.data_ptr()),
+            ctypes.c_void_p(reward.data_ptr()), ctypes.c_void_p(terminated.data_ptr()),
+            ctypes.c_void_p(truncated.data_ptr()), ctypes.c_void_p(stream),
+        )
+    _check(rc, "excenv_gym_step")
 
 
 def sim_ahead(env_id, solver_id, dtype, B, K, substeps, props: Props, control: Optional[Control],

@@ -126,6 +126,8 @@ class CoreEnvironment(ABC):
 
     def _leaf(self, x):
         """Property leaf -> Python float (broadcast) or [B] tensor of the working dtype on the device."""
+        if isinstance(x, bool):
+            return x
         if _is_array(x) and x.ndim >= 1:
             t = torch.as_tensor(x).to(device=self.device, dtype=self.dtype)
             return t
@@ -358,6 +360,87 @@ class CoreEnvironment(ABC):
         new_phys = self.PhysicalState(**dict(zip(self.STATE_FIELDS, st_out)))
         new_state = replace(state, physical_state=new_phys, additions=self._additions((self.batch_size,), True))
         return obs, new_state
+
+    def vmap_gym_step(self, state, action):
+        """vmap_step fused with generate_reward / generate_terminated / generate_truncated in ONE launch — what
+        GymWrapper.gym_step computes per step (gym_wrapper.py:88-130). Returns
+        (obs [B,O], reward [B,1], terminated [B,1] bool, truncated [B,TW] bool, new_state)."""
+        action = torch.as_tensor(action)
+        assert tuple(action.shape) == (self.batch_size, self.action_dim), (
+            "The action needs to be of shape (batch_size, action_dim) which is "
+            + f"{(self.batch_size, self.action_dim)}, but {tuple(action.shape)} is given"
+        )
+        B, S, O = self.batch_size, self.physical_state_dim, self._obs_dim()
+        props, keep = self._props_for(self.env_properties, B)
+        st_in = [self._t(getattr(state.physical_state, n), (B,)) for n in self.STATE_FIELDS]
+        act = self._t(action, (B, self.action_dim))
+        control, refs = self._control(state, (B,))
+        st_out = [torch.empty(B, dtype=self.dtype, device=self.device) for _ in range(S)]
+        obs = torch.empty((B, O), dtype=self.dtype, device=self.device)
+        reward = torch.empty((B, 1), dtype=self.dtype, device=self.device)
+        terminated = torch.empty((B, 1), dtype=torch.bool, device=self.device)
+        truncated = torch.empty((B, _native.truncated_width(self.ENV_ID, len(self.control_state))), dtype=torch.bool,
+                                device=self.device)
+        _native.gym_step(self.ENV_ID, self._solver.id, self.dtype, B, props, control, float(self.tau), st_in, act,
+                         st_out, obs, reward, terminated, truncated)
+        new_state = replace(state, physical_state=self.PhysicalState(**dict(zip(self.STATE_FIELDS, st_out))),
+                            additions=self._additions((B,), True))
+        return obs, reward, terminated, truncated, new_state
+
+    # ------------------------------------------------------------------ reward / truncated / terminated (torch mirrors)
+    ANGLE_FIELDS: tuple = ()
+
+    def generate_reward(self, state, action, env_properties):
+        """e.g. pendulum_env.py:297-309 (angles through sin/cos), mass_spring_damper_env.py:296-302. Trailing axis 1."""
+        ns = self.normalize_state(state, env_properties)
+        first = getattr(state.physical_state, self.STATE_FIELDS[0])
+        reward = torch.zeros_like(torch.as_tensor(first, dtype=self.dtype, device=self.device))
+        for name in self.control_state:
+            if name in self.ANGLE_FIELDS:
+                th, ref = getattr(state.physical_state, name), getattr(state.reference, name)
+                reward = reward + -((torch.sin(th) - torch.sin(ref)) ** 2 + (torch.cos(th) - torch.cos(ref)) ** 2)
+            else:
+                reward = reward + -((getattr(ns.physical_state, name) - getattr(ns.reference, name)) ** 2)
+        return reward[..., None]
+
+    def generate_truncated(self, state, env_properties):
+        """|obs| > 1 per observation column (e.g. pendulum_env.py:381-385)."""
+        return self.generate_observation(state, env_properties).abs() > 1
+
+    def generate_terminated(self, state, reward, env_properties):
+        """reward == 0 (e.g. pendulum_env.py:387-390)."""
+        return reward == 0
+
+    def vmap_generate_rew_trunc_term_ahead(self, states, actions):
+        """core_env.py:618-647 / :490-531 for trajectories returned by vmap_sim_ahead (elementwise torch ops over
+        the [B, K+1] leaves): reward [B,K,1] on rows 1.., truncated on all rows, terminated on rows 1..."""
+        actions = torch.as_tensor(actions)
+        assert actions.ndim == 3, "The actions need to have three dimensions: (batch_size, n_action_steps, action_dim)"
+        assert (
+            actions.shape[0] == self.batch_size
+        ), f"The first dimension does not correspond to the batch size which is {self.batch_size}, but {actions.shape[0]} is given"
+        assert (
+            actions.shape[-1] == self.action_dim
+        ), f"The last dimension does not correspond to the action dim which is {self.action_dim}, but {actions.shape[-1]} is given"
+        props = self._traj_properties()
+        cut = lambda tree: replace(tree, physical_state=self.PhysicalState(**{n: getattr(tree.physical_state, n)[:, 1:] for n in self.STATE_FIELDS}),
+                                   reference=self.PhysicalState(**{n: getattr(tree.reference, n)[:, 1:] for n in self.STATE_FIELDS}))
+        tail = cut(states)
+        reward = self.generate_reward(tail, None, props)
+        truncated = self.generate_truncated(states, props)
+        terminated = self.generate_terminated(tail, reward, props)
+        return reward, truncated, terminated
+
+    def _traj_properties(self):
+        """env_properties whose [B] leaves are reshaped to [B, 1] so they broadcast along the trajectory axis."""
+        from .tree import tree_map
+
+        def lift(x):
+            if _is_array(x) and x.ndim == 1 and x.shape[0] == self.batch_size:
+                return torch.as_tensor(x).to(device=self.device, dtype=self.dtype)[:, None]
+            return x
+
+        return tree_map(lift, self.env_properties)
 
     def _phys_shape(self, physical_state):
         leaves = [torch.as_tensor(getattr(physical_state, n)) for n in self.STATE_FIELDS]

@@ -79,6 +79,7 @@ class Pendulum(_SimpleEnv):
     ACTION_FIELDS = ("torque",)
     PARAM_FIELDS = ("g", "l", "m")
     DEFAULT_NORM_STATE = (1.0, 0.0)
+    ANGLE_FIELDS = ("theta",)
     PhysicalState = _dc("PhysicalState", STATE_FIELDS, "Physical state of the pendulum.")
     Action = _dc("Action", ACTION_FIELDS, "Action of the pendulum.")
     StaticParams = _dc("StaticParams", PARAM_FIELDS, "Static parameters of the pendulum.")
@@ -112,6 +113,7 @@ class CartPole(_SimpleEnv):
     ACTION_FIELDS = ("force",)
     PARAM_FIELDS = ("mu_p", "mu_c", "l", "m_p", "m_c", "g")
     DEFAULT_NORM_STATE = (0.0, 0.0, 1.0, 0.0)
+    ANGLE_FIELDS = ("theta",)
     DEFAULT_TAU = 2e-2
     PhysicalState = _dc("PhysicalState", STATE_FIELDS, "Physical state of the cart-pole.")
     Action = _dc("Action", ACTION_FIELDS, "Action of the cart-pole.")
@@ -131,6 +133,7 @@ class Acrobot(_SimpleEnv):
     ACTION_FIELDS = ("torque",)
     PARAM_FIELDS = ("g", "l_1", "l_2", "m_1", "m_2", "l_c1", "l_c2", "I_1", "I_2")
     DEFAULT_NORM_STATE = (1.0, 0.0, 0.0, 0.0)
+    ANGLE_FIELDS = ("theta_1", "theta_2")
     DEFAULT_TAU = 1e-3
     PhysicalState = _dc("PhysicalState", STATE_FIELDS, "Physical state of the acrobot.")
     Action = _dc("Action", ACTION_FIELDS, "Action of the acrobot.")
@@ -159,6 +162,15 @@ class FluidTank(_SimpleEnv):
     DEFAULT_PHYSICAL_NORMALIZATIONS = {"height": (0, 3)}
     DEFAULT_ACTION_NORMALIZATIONS = {"inflow": (0, 0.2)}
     DEFAULT_STATIC_PARAMS = {"base_area": math.pi, "orifice_area": math.pi * 0.1**2, "c_d": 0.6, "g": 9.81}
+
+    def generate_truncated(self, state, env_properties):
+        """fluid_tank_env.py:325-328: constant 0."""
+        h = torch.as_tensor(state.physical_state.height)
+        return torch.zeros(tuple(h.shape) + (1,), dtype=torch.bool, device=h.device)
+
+    def generate_terminated(self, state, reward, env_properties):
+        """fluid_tank_env.py:330-333: constant False."""
+        return torch.zeros_like(reward, dtype=torch.bool)
 
     @property
     def states_description(self):
@@ -329,6 +341,36 @@ class PMSM(CoreEnvironment):
                                 PRNGKey=self._nan(shape) if key is None else key,
                                 additions=self._additions(shape, False), reference=self.PhysicalState(**ref))
         return self.denormalize_state(norm_state, env_properties)
+
+    def generate_truncated(self, system_state, env_properties):
+        """pmsm_env.py:972-979: normalised current magnitude > 1."""
+        ns = self.normalize_state(system_state, env_properties)
+        i_s = torch.sqrt(ns.physical_state.i_d ** 2 + ns.physical_state.i_q ** 2)
+        return (i_s > 1)[..., None]
+
+    def generate_terminated(self, system_state, reward, env_properties):
+        """pmsm_env.py:981-983."""
+        return self.generate_truncated(system_state, env_properties)
+
+    def generate_reward(self, state, action, env_properties):
+        """pmsm_env.py:985-1037 (current_reward_func / torque_reward_func with gamma = 0.85)."""
+        ns = self.normalize_state(state, env_properties)
+        p, r = ns.physical_state, ns.reference
+        reward = torch.zeros_like(p.i_d)
+        if "i_d" in self.control_state and "i_q" in self.control_state:
+            mse = 0.5 * (p.i_d - r.i_d) ** 2 + 0.5 * (p.i_q - r.i_q) ** 2
+            reward = reward + -1 * (mse * (1 - 0.85))
+        if "torque" in self.control_state:
+            i_s = torch.sqrt(p.i_d ** 2 + p.i_q ** 2)
+            i_n, i_d_plus, tol = 1.0, 0.2, 0.01
+            rew = torch.zeros_like(r.torque)
+            rew = torch.where(i_s > 1, -1 * i_s.abs(), rew)
+            rew = torch.where((i_s < i_n) & (p.i_d > i_d_plus), -0.5 * ((p.i_d - i_d_plus) / (i_n - i_d_plus)), rew)
+            ad = (p.torque - r.torque).abs()
+            rew = torch.where((i_s < i_n) & (p.i_d < i_d_plus) & (ad > tol), 0.5 * (1 - ((r.torque - p.torque) / 2).abs()), rew)
+            rew = torch.where((i_s < i_n) & (p.i_d < i_d_plus) & (ad < tol), 1 - 0.5 * i_s, rew)
+            reward = reward + rew * (1 - 0.85)
+        return reward[..., None]
 
     @property
     def action_description(self):

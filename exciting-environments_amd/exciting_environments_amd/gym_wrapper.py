@@ -1,0 +1,114 @@
+"""GymWrapper — host-side mirror of reference exciting_environments/gym_wrapper.py: a stateful wrapper whose
+``step(action)`` returns ``(observation, reward, terminated, truncated)``. The per-step work (ODE step + reward +
+terminated + truncated) is ONE fused HIP launch (``excenv_gym_step``). The reference-trajectory generator
+(``update_ref`` / ``generate_new_ref``, gym_wrapper.py:170-192) draws from ``torch`` generators, not JAX's Threefry
+stream, so reference values differ from the reference's for the same seed (deviations)."""
+from __future__ import annotations
+
+from dataclasses import fields, replace
+
+import torch
+
+from .registration import EnvironmentRegistry
+
+
+class GymWrapper:
+    def __init__(self, env, control_state=None, generate_reward=None, generate_terminated=None,
+                 generate_truncated=None, ref_params=None):
+        self.env = env
+        if control_state is None:
+            print(f"No chosen control state in the GymWrapper. Control state is set to {self.env.control_state}.")
+            self.control_state = self.env.control_state
+        else:
+            assert type(control_state) == list, "Control state has to be a list."
+            valid = [f.name for f in fields(self.env.PhysicalState)]
+            for i in control_state:
+                assert i in valid, f"Given control state {i} is no valid physical state {valid}."
+            self.control_state = control_state
+            self.env.control_state = control_state
+        self.ref_gen = False
+        _, init_state = self.env.vmap_reset()
+        self.ref_params = ref_params or {"hold_steps_min": 10, "hold_steps_max": 1000}
+        self.reference_hold_steps = torch.zeros((self.env.batch_size, 1), dtype=torch.int64, device=self.env.device)
+        self.state = init_state
+        # user-supplied callables (state, action/reward, env_properties) -> tensor replace the fused outputs
+        self.generate_reward = generate_reward
+        self.generate_truncated = generate_truncated
+        self.generate_terminated = generate_terminated
+        self._ref_rng = None
+
+    @classmethod
+    def from_env(cls, env_type: EnvironmentRegistry, **env_kwargs):
+        """Creates GymWrapper with environment from EnvironmentRegistry (gym_wrapper.py:61-65)."""
+        return cls(env_type.make(**env_kwargs))
+
+    def step(self, action):
+        """One simulation step (gym_wrapper.py:67-86): observation [B,obs_dim], reward [B,1], terminated [B,1],
+        truncated [B, n_flags]."""
+        obs, reward, terminated, truncated, self.state, self.reference_hold_steps = self.gym_step(
+            action, self.state, self.reference_hold_steps
+        )
+        return obs, reward, terminated, truncated
+
+    def gym_step(self, action, state, reference_hold_steps):
+        """gym_wrapper.py:88-130."""
+        env = self.env
+        custom = self.generate_reward or self.generate_terminated or self.generate_truncated
+        regen = len(self.control_state) and self.ref_gen
+        if not custom and not regen:
+            obs, reward, terminated, truncated, state = env.vmap_gym_step(state, action)
+            return obs, reward, terminated, truncated, state, reference_hold_steps
+        obs, state = env.vmap_step(state, action)
+        if regen:
+            state, reference_hold_steps = self.update_ref(state, reference_hold_steps)
+        ep = env.env_properties
+        reward = (self.generate_reward or env.generate_reward)(state, action, ep)
+        terminated = (self.generate_terminated or env.generate_terminated)(state, reward, ep)
+        truncated = (self.generate_truncated or env.generate_truncated)(state, ep)
+        return obs, reward, terminated, truncated, state, reference_hold_steps
+
+    def reset(self, rng_env=None, rng_ref=None, initial_state=None):
+        """Resets the environment to a default / random / passed initial state and (re)arms the reference generator
+        when `rng_ref` is given (gym_wrapper.py:132-168)."""
+        env = self.env
+        if initial_state is not None:
+            _, state = env.vmap_reset(initial_state=initial_state)
+        else:
+            _, state = env.vmap_reset(rng_env)
+        if rng_ref is not None:
+            gen = rng_ref
+            if not isinstance(rng_ref, torch.Generator):
+                gen = torch.Generator(device=env.device)
+                gen.manual_seed(int(rng_ref))
+            self._ref_rng = gen
+            self.ref_gen = True
+            need = torch.ones((env.batch_size, 1), dtype=torch.bool, device=env.device)
+            state, self.reference_hold_steps = self.generate_new_ref(state, need, self.reference_hold_steps)
+        else:
+            self.ref_gen = False
+            print("Since no PRNGKey for reference was provided, reference generation is deactivated.")
+        self.state = state
+        return env.generate_observation(state, env.env_properties), {}
+
+    def update_ref(self, state, hold_steps):
+        """gym_wrapper.py:170-175: draw a new reference where the hold counter reached zero, then count down."""
+        state, hold_steps = self.generate_new_ref(state, hold_steps == 0, hold_steps)
+        return state, hold_steps - 1
+
+    def generate_new_ref(self, state, mask, hold_steps):
+        """gym_wrapper.py:177-192: reference := a random initial state's controlled fields; hold ~ U{min..max-1}."""
+        env = self.env
+        init = env.vmap_init_state(self._ref_rng)
+        m = mask[:, 0]
+        ref = {n: getattr(state.reference, n) for n in env.STATE_FIELDS}
+        for name in self.control_state:
+            ref[name] = torch.where(m, getattr(init.physical_state, name), ref[name])
+        new_hold = torch.randint(self.ref_params["hold_steps_min"], self.ref_params["hold_steps_max"],
+                                 (env.batch_size, 1), generator=self._ref_rng, device=env.device)
+        return replace(state, reference=env.PhysicalState(**ref)), torch.where(mask, new_hold, hold_steps)
+
+    def render(self, *_, **__):
+        raise NotImplementedError("To be implemented!")
+
+    def close(self):
+        raise NotImplementedError("To be implemented!")

@@ -122,6 +122,21 @@ int excenv_step(int env, int solver, int dtype, int64_t B,
                 const void* const* state_in, const void* action,
                 void* const* state_out, void* obs, void* stream);
 
+/* ---- replaces GymWrapper.gym_step (gym_wrapper.py:88-130): vmap_step fused with the environment's
+ * generate_reward / generate_terminated / generate_truncated (e.g. pendulum_env.py:297-309,381-390,
+ * pmsm_env.py:972-1037) so the new state is not read a second time.
+ *   reward     : [B] values of the working dtype (the reference's [B,1])
+ *   terminated : [B] bytes (0/1)
+ *   truncated  : [B][excenv_truncated_width(env, n_control)] bytes (0/1): |obs| > 1 per observation column; one flag
+ *                for PMSM (|i_dq| > 1 in normalised units) and FluidTank (constant 0)
+ * The reference-generator (update_ref / generate_new_ref, JAX Threefry) is not part of this entry point. */
+int32_t excenv_truncated_width(int env, int32_t n_control);
+int excenv_gym_step(int env, int solver, int dtype, int64_t B,
+                    const excenv_props_t* props, const excenv_control_t* control, double tau,
+                    const void* const* state_in, const void* action,
+                    void* const* state_out, void* obs, void* reward, uint8_t* terminated, uint8_t* truncated,
+                    void* stream);
+
 /* ---- replaces CoreEnvironment.vmap_sim_ahead (core_env.py:571-616) --------------------
  * and PMSM.sim_ahead (pmsm_env.py:746-801). One persistent launch runs all N = K*substeps
  * solver steps of step size obs_stepsize; action k is held for `substeps` solver steps.

@@ -186,6 +186,37 @@ def step(env: str, solver: str, state: Sequence[np.ndarray], action: np.ndarray,
     return obs, st_out
 
 
+def gym_step(env: str, solver: str, state: Sequence[np.ndarray], action: np.ndarray, props: Props, tau: float,
+             control=None):
+    """vmap_step + generate_reward / generate_terminated / generate_truncated (GymWrapper.gym_step).
+    Returns (obs, new_state, reward [B,1], terminated [B,1] bool, truncated [B,TW] bool)."""
+    dtype = np.dtype(state[0].dtype)
+    B = state[0].shape[0]
+    eid = ENV_IDS[env]
+    S, A, O, _ = ENV_DIMS[eid]
+    keep: list = []
+    ctl = _make_control(env, control, dtype, B, keep)
+    nc = len(control) if control else 0
+    TW = 1 if env in ("pmsm", "fluid_tank") else O + nc
+    st_in = [np.ascontiguousarray(s, dtype=dtype) for s in state]
+    act = np.ascontiguousarray(action, dtype=dtype).reshape(B, A)
+    st_out = [np.empty(B, dtype=dtype) for _ in range(S)]
+    obs = np.empty((B, O + nc), dtype=dtype)
+    reward = np.empty(B, dtype=dtype)
+    term = np.empty(B, dtype=np.uint8)
+    trunc = np.empty((B, TW), dtype=np.uint8)
+    lib().oracle_gym_step.restype = ctypes.c_int
+    rc = lib().oracle_gym_step(
+        ctypes.c_int(eid), ctypes.c_int(SOLVER_IDS[solver]), ctypes.c_int(DTYPE_IDS[dtype]), ctypes.c_int64(B),
+        ctypes.byref(props), ctypes.byref(ctl) if ctl else None, ctypes.c_double(tau),
+        _ptr_array(st_in), ctypes.c_void_p(act.ctypes.data), _ptr_array(st_out), ctypes.c_void_p(obs.ctypes.data),
+        ctypes.c_void_p(reward.ctypes.data), ctypes.c_void_p(term.ctypes.data), ctypes.c_void_p(trunc.ctypes.data),
+    )
+    if rc != 0:
+        raise RuntimeError(f"oracle_gym_step failed rc={rc}")
+    return obs, st_out, reward[:, None], term.astype(bool)[:, None], trunc.astype(bool)
+
+
 def sim_ahead(env: str, solver: str, state: Sequence[np.ndarray], actions: np.ndarray, props: Props,
               obs_stepsize: float, env_tau: Optional[float] = None, substeps: int = 1, semantics: int = SEM_STEP,
               control=None, want_states: bool = True, out=None):

@@ -65,6 +65,7 @@ static const double TSIT5_B[6] = {0.09646076681806523, 0.01, 0.4798896504144996,
 #define R_ATAN2 atan2f
 #define R_FMOD fmodf
 #define R_FMA fmaf
+#define R_ABS fabsf
 #include "oracle_body.inc"
 #undef REAL
 #undef FN
@@ -74,6 +75,7 @@ static const double TSIT5_B[6] = {0.09646076681806523, 0.01, 0.4798896504144996,
 #undef R_ATAN2
 #undef R_FMOD
 #undef R_FMA
+#undef R_ABS
 
 /* ---- double instantiation ---- */
 #define REAL double
@@ -84,6 +86,7 @@ static const double TSIT5_B[6] = {0.09646076681806523, 0.01, 0.4798896504144996,
 #define R_ATAN2 atan2
 #define R_FMOD fmod
 #define R_FMA fma
+#define R_ABS fabs
 #include "oracle_body.inc"
 #undef REAL
 #undef FN
@@ -129,6 +132,20 @@ int oracle_step(int env, int solver, int dtype, int64_t B, const excenv_props_t*
   return dtype == EXCENV_F32
              ? oracle_step_f32(&ENVS[env], solver, B, props, control, tau, state_in, action, state_out, obs)
              : oracle_step_f64(&ENVS[env], solver, B, props, control, tau, state_in, action, state_out, obs);
+}
+
+/* host-pointer twin of excenv_gym_step */
+int oracle_gym_step(int env, int solver, int dtype, int64_t B, const excenv_props_t* props,
+                    const excenv_control_t* control, double tau, const void* const* state_in, const void* action,
+                    void* const* state_out, void* obs, void* reward, uint8_t* terminated, uint8_t* truncated) {
+  int rc = check_common(env, solver, dtype, B);
+  if (rc) return rc;
+  if (!props || !state_in || !action || !state_out || !obs || !reward || !terminated || !truncated) return EXCENV_ENULL;
+  if (control && control->n_control == 0) control = NULL;
+  return dtype == EXCENV_F32 ? oracle_gym_step_f32(&ENVS[env], solver, B, props, control, tau, state_in, action, state_out,
+                                                   obs, reward, terminated, truncated)
+                             : oracle_gym_step_f64(&ENVS[env], solver, B, props, control, tau, state_in, action, state_out,
+                                                   obs, reward, terminated, truncated);
 }
 
 /* host-pointer twin of excenv_sim_ahead */
