@@ -98,6 +98,30 @@ def _require_device(t: torch.Tensor, what: str):
         )
 
 
+def _raw_stream(device: torch.device) -> int:
+    """hipStream_t of torch's current stream on `device` (the fast private accessor when torch has it)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+    except AttributeError:  # pragma: no cover
+        return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on_device:
+    """`with torch.cuda.device(d)` only when d is not already current (saves a few us per launch)."""
+
+    def __init__(self, device):
+        idx = device.index
+        self.ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 def _ptrs(tensors: Sequence[torch.Tensor]):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
@@ -135,8 +159,8 @@ def step(env_id, solver_id, dtype, B, props: Props, control: Optional[Control], 
          state_in: Sequence[torch.Tensor], action: torch.Tensor, state_out: Sequence[torch.Tensor],
          obs: torch.Tensor):
     _require_device(action, "vmap_step")
-    with torch.cuda.device(action.device):
-        stream = torch.cuda.current_stream(action.device).cuda_stream
+    with _on_device(action.device):
+        stream = _raw_stream(action.device)
         rc = lib().excenv_step(
             ctypes.c_int(env_id), ctypes.c_int(solver_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B),
             ctypes.byref(props), ctypes.byref(control) if control is not None else None, ctypes.c_double(tau),
@@ -154,8 +178,8 @@ def gym_step(env_id, solver_id, dtype, B, props: Props, control: Optional[Contro
              state_in: Sequence[torch.Tensor], action: torch.Tensor, state_out: Sequence[torch.Tensor],
              obs: torch.Tensor, reward: torch.Tensor, terminated: torch.Tensor, truncated: torch.Tensor):
     _require_device(action, "gym_step")
-    with torch.cuda.device(action.device):
-        stream = torch.cuda.current_stream(action.device).cuda_stream
+    with _on_device(action.device):
+        stream = _raw_stream(action.device)
         rc = lib().excenv_gym_step(
             ctypes.c_int(env_id), ctypes.c_int(solver_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B),
             ctypes.byref(props), ctypes.byref(control) if control is not None else None, ctypes.c_double(tau),
@@ -172,8 +196,8 @@ def sim_ahead(env_id, solver_id, dtype, B, K, substeps, props: Props, control: O
               traj_layout: int, last_state: Sequence[torch.Tensor], semantics: int,
               workspace: Optional[torch.Tensor] = None):
     _require_device(obs_traj, "vmap_sim_ahead")
-    with torch.cuda.device(obs_traj.device):
-        stream = torch.cuda.current_stream(obs_traj.device).cuda_stream
+    with _on_device(obs_traj.device):
+        stream = _raw_stream(obs_traj.device)
         rc = lib().excenv_sim_ahead_ws(
             ctypes.c_int(env_id), ctypes.c_int(solver_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B),
             ctypes.c_int64(K), ctypes.c_int32(substeps), ctypes.byref(props),

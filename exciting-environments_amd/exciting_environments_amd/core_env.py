@@ -98,6 +98,8 @@ class CoreEnvironment(ABC):
         # env-major buffers: True = transpose through a scratch workspace (fast), False = generic-stride kernel path
         self.env_major_workspace = True
         self._packed_props = None
+        self._flag_cache = {}
+        self._obs_dim_cache = None
 
     # ------------------------------------------------------------------ properties plumbing
     def create_in_axes_dataclass(self, dataclass_obj):
@@ -174,6 +176,9 @@ class CoreEnvironment(ABC):
         return self._pack_props(env_properties, B)
 
     def _t(self, x, shape=None):
+        if (isinstance(x, torch.Tensor) and x.dtype == self.dtype and x.device == self.device and x.is_contiguous()
+                and (shape is None or tuple(x.shape) == tuple(shape))):
+            return x  # fast path: already a device tensor of the working dtype
         t = torch.as_tensor(x).to(device=self.device, dtype=self.dtype)
         if shape is not None and tuple(t.shape) != tuple(shape):
             t = t.expand(shape)
@@ -220,8 +225,15 @@ class CoreEnvironment(ABC):
         return torch.full(shape, float("nan"), dtype=self.dtype, device=self.device)
 
     def _additions(self, shape, active: bool):
-        return self.Additions(solver_state=None,
-                              active_solver_state=torch.full(shape, active, dtype=torch.bool, device=self.device))
+        # constant flag leaves are shared between states (states are immutable by contract, like the reference's
+        # pytrees), so stepping does not launch a fill kernel per call
+        key = (tuple(shape), bool(active))
+        flag = self._flag_cache.get(key)
+        if flag is None:
+            flag = torch.full(shape, active, dtype=torch.bool, device=self.device)
+            if len(self._flag_cache) < 64:
+                self._flag_cache[key] = flag
+        return self.Additions(solver_state=None, active_solver_state=flag)
 
     def _random_norm_state(self, rng, shape):
         """Random normalised initial state (e.g. pendulum_env.py:270-276). `rng` is a torch.Generator or an int
@@ -308,6 +320,8 @@ class CoreEnvironment(ABC):
 
     # ------------------------------------------------------------------ the hot path
     def _control(self, state, shape):
+        if not self.control_state:
+            return None, []
         idx = [self.STATE_FIELDS.index(n) for n in self.control_state]
         refs = [self._t(getattr(state.reference, n), shape) for n in self.control_state]
         return _native.make_control(idx, refs), refs
@@ -318,14 +332,18 @@ class CoreEnvironment(ABC):
         st_in = [self._t(getattr(state.physical_state, n), (B,)) for n in self.STATE_FIELDS]
         act = self._t(action, (B, self.action_dim))
         control, refs = self._control(state, (B,))
-        st_out = [torch.empty(B, dtype=self.dtype, device=self.device) for _ in range(S)]
-        obs = torch.empty((B, O), dtype=self.dtype, device=self.device)
+        pad = (-B) % 4  # keep every leaf 16-byte aligned inside the single allocation
+        buf = torch.empty(S * (B + pad) + B * O, dtype=self.dtype, device=self.device)
+        st_out = [buf[j * (B + pad): j * (B + pad) + B] for j in range(S)]
+        obs = buf[S * (B + pad):].view(B, O)
         _native.step(self.ENV_ID, self._solver.id, self.dtype, B, props, control, float(self.tau), st_in, act,
                      st_out, obs)
         return obs, st_out
 
     def _obs_dim(self):
-        return _native.env_dims(self.ENV_ID)[2] + len(self.control_state)
+        if self._obs_dim_cache is None or self._obs_dim_cache[0] != len(self.control_state):
+            self._obs_dim_cache = (len(self.control_state), _native.env_dims(self.ENV_ID)[2] + len(self.control_state))
+        return self._obs_dim_cache[1]
 
     def step(self, state, action_norm, env_properties):
         """One simulation step of a single environment (core_env.py:393-425)."""

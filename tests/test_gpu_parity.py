@@ -349,6 +349,36 @@ def test_transpose_kernel(shape):
         assert torch.equal(_native.transpose(x), x.t().contiguous())
 
 
+def test_entry_points_are_hip_graph_capturable():
+    """The C ABI only enqueues kernels on the caller's stream (no allocation, no synchronisation): a chain of
+    vmap_step / vmap_gym_step / vmap_sim_ahead calls can be captured into a HIP graph and replayed."""
+    B, K = 2048, 12
+    env, props, keep, spec = make_env("pmsm", B, torch.float32)
+    st = random_state("pmsm", B, np.float32, spec, seed=301)
+    acts = env.new_actions_buffer(K)
+    acts.copy_(torch.as_tensor(np.random.default_rng(302).uniform(-1, 1, (B, K, 2)).astype(np.float32), device=env.device))
+    s0 = to_state(env, st)
+    # eager reference
+    s = s0
+    for k in range(4):
+        o_ref, s = env.vmap_step(s, acts[:, k].contiguous())
+    obs_ref, _, last_ref = env.vmap_sim_ahead(s, acts, env.tau, env.tau)
+    a4 = [acts[:, k].contiguous() for k in range(4)]
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s = s0
+        for k in range(4):
+            o_g, s = env.vmap_step(s, a4[k])
+        obs_g, _, last_g = env.vmap_sim_ahead(s, acts, env.tau, env.tau)
+    o_g.zero_(); obs_g.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o_g, o_ref) and torch.equal(obs_g, obs_ref)
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(last_g.physical_state, n), getattr(last_ref.physical_state, n))
+
+
 # ------------------------------------------------------------------------------------------------ device math
 def test_device_sincos_fp32_within_2ulp():
     from exciting_environments_amd import _native

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Where does the host time of one vmap_step go at small batch sizes? (cProfile over 3000 steps, B = 1024)"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "exciting-environments_amd")]
+import torch
+
+from exciting_environments_amd import EnvironmentRegistry
+
+for name in ("PENDULUM", "PMSM"):
+    env = getattr(EnvironmentRegistry, name).make(batch_size=1024, device="cuda:0")
+    _, state = env.vmap_reset()
+    act = torch.zeros((1024, env.action_dim), device="cuda:0")
+    for _ in range(50):
+        obs, state = env.vmap_step(state, act)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3000
+    for _ in range(n):
+        obs, state = env.vmap_step(state, act)
+    torch.cuda.synchronize()
+    print(f"{name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per vmap_step (B=1024, eager)")
+    # HIP graph replay of 16 chained steps
+    g = torch.cuda.CUDAGraph()
+    s_in = state
+    with torch.cuda.graph(g):
+        s = s_in
+        for _ in range(16):
+            o, s = env.vmap_step(s, act)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        g.replay()
+    torch.cuda.synchronize()
+    print(f"{name}: {(time.perf_counter() - t0) / (200 * 16) * 1e6:.1f} us per vmap_step inside a 16-step HIP graph")
+
+env = EnvironmentRegistry.PENDULUM.make(batch_size=1024, device="cuda:0")
+_, state = env.vmap_reset()
+act = torch.zeros((1024, 1), device="cuda:0")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(3000):
+    obs, state = env.vmap_step(state, act)
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
