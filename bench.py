@@ -73,6 +73,7 @@ def build_env(args, device, rank):
         del flat
     env.traj_layout = args.traj_layout
     env.env_major_workspace = not getattr(args, "no_workspace", False)
+    env.store_state_trajectory = not getattr(args, "obs_only", False)
     return env, state, actions, B, Kc, reg, solver, dtype
 
 
@@ -149,6 +150,7 @@ def main():
     ap.add_argument("--lds-pad", type=int, default=0, help="dynamic LDS bytes per workgroup (occupancy cap experiment)")
     ap.add_argument("--path", default="sim_ahead", choices=["sim_ahead", "step"],
                     help="sim_ahead: one persistent launch per bench step (headline); step: one vmap_step launch per bench step")
+    ap.add_argument("--obs-only", action="store_true", help="skip the state trajectories (not the reference's full outputs)")
     ap.add_argument("--no-workspace", action="store_true", help="env-major buffers: use the generic-stride kernel path")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -234,7 +236,7 @@ def main():
         Kc = 1
         bytes_per_step = _native.step_bytes(env.ENV_ID, dtype)
     else:
-        bytes_per_step = _native.sim_ahead_bytes(env.ENV_ID, dtype, True)
+        bytes_per_step = _native.sim_ahead_bytes(env.ENV_ID, dtype, not args.obs_only)
     algo_bytes = bytes_per_step * B * Kc
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if args.steps else float("nan")
 
@@ -267,7 +269,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{reg} {solver} {'fp32' if dtype == torch.float32 else 'fp64'} vmap_{args.path}, "
-                            f"batch {B} per GPU, {Kc} solver steps per launch, full outputs (obs + state trajectories)",
+                            f"batch {B} per GPU, {Kc} solver steps per launch, "
+                            + ("observations only" if args.obs_only else "full outputs (obs + state trajectories)"),
                 "batch_per_gpu": B, "global_batch": B * world, "chunk_steps": Kc, "semantics": args.semantics,
                 "traj_layout": args.traj_layout, "action_layout": args.action_layout,
                 "parallelism": f"batch-sharded x{world}" + (", all-gather(final obs) overlapped" if gatherer else ""),

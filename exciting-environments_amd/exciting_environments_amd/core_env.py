@@ -97,6 +97,9 @@ class CoreEnvironment(ABC):
         self.sim_ahead_semantics = "ahead"
         # env-major buffers: True = transpose through a scratch workspace (fast), False = generic-stride kernel path
         self.env_major_workspace = True
+        # False: vmap_sim_ahead skips the physical-state trajectories (`states` is None; 40 instead of 68 bytes per
+        # PMSM env-step). The reference always returns them, so the default is True.
+        self.store_state_trajectory = True
         self._packed_props = None
         self._flag_cache = {}
         self._obs_dim_cache = None
@@ -503,23 +506,24 @@ class CoreEnvironment(ABC):
             actions = actions.contiguous()
             a_layout = _native.LAYOUT_ENV_MAJOR
 
+        want_states = self.store_state_trajectory
         if self.traj_layout == "lane_major":
             obs_buf = torch.empty((N + 1, OW, B), dtype=self.dtype, device=self.device)
-            st_buf = [torch.empty((N + 1, B), dtype=self.dtype, device=self.device) for _ in range(S)]
+            st_buf = [torch.empty((N + 1, B), dtype=self.dtype, device=self.device) for _ in range(S)] if want_states else None
             t_layout = _native.LAYOUT_LANE_MAJOR
             observations = obs_buf.permute(2, 0, 1)
-            st_views = [b.t() for b in st_buf]
+            st_views = [b.t() for b in st_buf] if want_states else None
         elif self.traj_layout == "tiled":
             # opt-in, NOT reference-shaped: tiles of T envs, each tile lane-major -> views [B/T, T, N+1, OW] / [B/T, T, N+1]
             assert B % T == 0, f"traj_layout='tiled' needs batch_size % {T} == 0"
             obs_buf = torch.empty((B // T, N + 1, OW, T), dtype=self.dtype, device=self.device)
-            st_buf = [torch.empty((B // T, N + 1, T), dtype=self.dtype, device=self.device) for _ in range(S)]
+            st_buf = [torch.empty((B // T, N + 1, T), dtype=self.dtype, device=self.device) for _ in range(S)] if want_states else None
             t_layout = _native.LAYOUT_TILED
             observations = obs_buf.permute(0, 3, 1, 2)
-            st_views = [b.permute(0, 2, 1) for b in st_buf]
+            st_views = [b.permute(0, 2, 1) for b in st_buf] if want_states else None
         elif self.traj_layout == "env_major":
             obs_buf = torch.empty((B, N + 1, OW), dtype=self.dtype, device=self.device)
-            st_buf = [torch.empty((B, N + 1), dtype=self.dtype, device=self.device) for _ in range(S)]
+            st_buf = [torch.empty((B, N + 1), dtype=self.dtype, device=self.device) for _ in range(S)] if want_states else None
             t_layout = _native.LAYOUT_ENV_MAJOR
             observations, st_views = obs_buf, st_buf
         else:
@@ -531,7 +535,7 @@ class CoreEnvironment(ABC):
             # env-major (row-major) buffers: let the library transpose through a scratch buffer instead of issuing
             # scattered 4-byte accesses (excenv_sim_ahead_ws)
             nbytes = _native.sim_ahead_workspace_bytes(self.ENV_ID, self.dtype, B, K, sub, len(self.control_state),
-                                                       a_layout, t_layout, True)
+                                                       a_layout, t_layout, want_states)
             if nbytes > 0:
                 workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         _native.sim_ahead(self.ENV_ID, self._solver.id, self.dtype, B, K, sub, props, control, float(obs_stepsize),
@@ -565,7 +569,7 @@ class CoreEnvironment(ABC):
         )
         obs, st_views, last, N = self._run_sim_ahead(init_state, actions[None], env_properties, obs_stepsize,
                                                      action_stepsize, 1)
-        states = self._traj_state(init_state, [v[0] for v in st_views], (), N)
+        states = self._traj_state(init_state, [v[0] for v in st_views], (), N) if st_views is not None else None
         last_state = replace(init_state, physical_state=self.PhysicalState(
             **{n: t.reshape(()) for n, t in zip(self.STATE_FIELDS, last)}), additions=self._additions((), True))
         return obs[0], states, last_state
@@ -594,7 +598,9 @@ class CoreEnvironment(ABC):
         B = self.batch_size
         obs, st_views, last, N = self._run_sim_ahead(init_state, actions, self.env_properties, obs_stepsize,
                                                      action_stepsize, B)
-        if self.traj_layout == "tiled":
+        if st_views is None:
+            states = None
+        elif self.traj_layout == "tiled":
             states = self.State(physical_state=self.PhysicalState(**dict(zip(self.STATE_FIELDS, st_views))),
                                 PRNGKey=None, additions=None, reference=None)
         else:

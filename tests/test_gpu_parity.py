@@ -349,6 +349,22 @@ def test_transpose_kernel(shape):
         assert torch.equal(_native.transpose(x), x.t().contiguous())
 
 
+def test_observations_only_variant():
+    """store_state_trajectory = False: same observations and last_state, no state trajectories written."""
+    B, K = 2048, 17
+    for layout in ("lane_major", "env_major"):
+        env, props, keep, spec = make_env("pmsm", B, torch.float32)
+        env.traj_layout = layout
+        st = random_state("pmsm", B, np.float32, spec, seed=311)
+        acts = torch.as_tensor(np.random.default_rng(312).uniform(-1, 1, (B, K, 2)).astype(np.float32), device=env.device)
+        o_full, s_full, l_full = env.vmap_sim_ahead(to_state(env, st), acts, env.tau, env.tau)
+        env.store_state_trajectory = False
+        o_only, s_only, l_only = env.vmap_sim_ahead(to_state(env, st), acts, env.tau, env.tau)
+        assert s_only is None and torch.equal(o_only, o_full)
+        for n in env.STATE_FIELDS:
+            assert torch.equal(getattr(l_only.physical_state, n), getattr(l_full.physical_state, n))
+
+
 def test_entry_points_are_hip_graph_capturable():
     """The C ABI only enqueues kernels on the caller's stream (no allocation, no synchronisation): a chain of
     vmap_step / vmap_gym_step / vmap_sim_ahead calls can be captured into a HIP graph and replayed."""

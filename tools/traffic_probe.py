@@ -21,6 +21,7 @@ ap.add_argument("--action-layout", default="lane_major")
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--vec", type=int, default=0)
+ap.add_argument("--path", default="sim_ahead")
 a = ap.parse_args()
 a.semantics = "ahead"
 torch.cuda.set_device(0)
@@ -37,5 +38,8 @@ if a.vec:
     from exciting_environments_amd import _native
     _native.set_tuning(0, a.vec)
 for _ in range(a.launches):
-    obs, states, state = env.vmap_sim_ahead(state, actions, env.tau, env.tau)
+    if a.path == "step":
+        obs, state = env.vmap_step(state, actions[:, 0, :].contiguous())
+    else:
+        obs, states, state = env.vmap_sim_ahead(state, actions, env.tau, env.tau)
 torch.cuda.synchronize()
