@@ -10,8 +10,9 @@ every step reuses) are resident in HBM before the timed region.
     python bench.py --gpus N --steps K --warmup W
 
 N > 1: launched by torch.distributed.run, one rank per GPU, batch sharded (weak scaling: 2^22 envs per rank),
-no collective on the stepping path; the final observation row of every chunk is all-gathered (RCCL) on a side
-stream, overlapped with the next chunk (`--gather none` disables it).
+no collective on the stepping path; the observations are reassembled with ONE RCCL all-gather of the final
+observation row at the end of the timed region (`--gather chunk`: after every chunk on a side stream, overlapped;
+`--gather none`: never).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -145,7 +146,9 @@ def main():
     ap.add_argument("--semantics", default="ahead", choices=["ahead", "step"])
     ap.add_argument("--traj-layout", default="lane_major", choices=["lane_major", "env_major", "tiled"])
     ap.add_argument("--action-layout", default="lane_major", choices=["lane_major", "env_major", "tiled"])
-    ap.add_argument("--gather", default="final", choices=["final", "none"])
+    ap.add_argument("--gather", default="end", choices=["end", "chunk", "none"],
+                    help="N>1: all-gather (RCCL) of observations — 'end': once, the final row of the last chunk, inside the "
+                         "timed region; 'chunk': after every chunk on a side stream, overlapped; 'none'")
     ap.add_argument("--vec", type=int, default=0, help="envs per lane (0 auto)")
     ap.add_argument("--lds-pad", type=int, default=0, help="dynamic LDS bytes per workgroup (occupancy cap experiment)")
     ap.add_argument("--path", default="sim_ahead", choices=["sim_ahead", "step"],
@@ -177,7 +180,7 @@ def main():
         _native.set_tuning(0, args.vec)
     if args.lds_pad:
         _native.set_tuning(1, args.lds_pad)
-    use_gather = args.gather == "final" and (world > 1 or os.environ.get("EXCENV_BENCH_FORCE_GATHER") == "1")
+    use_gather = args.gather != "none" and (world > 1 or os.environ.get("EXCENV_BENCH_FORCE_GATHER") == "1")
     if use_gather and not dist.is_initialized():  # 1-rank rehearsal of the collective path
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -187,18 +190,25 @@ def main():
 
     step_actions = [actions[:, k, :].contiguous() for k in range(min(Kc, 8))] if args.path == "step" else None
     step_count = [0]
+    last_obs = [None]
+
+    def final_row(obs):
+        if obs.ndim == 2:
+            return obs
+        return obs[:, -1, :] if obs.ndim == 3 else obs[:, :, -1, :].reshape(B, -1)
 
     def one_step(st):
         nonlocal gathered
         if args.path == "step":
             obs, last = env.vmap_step(st, step_actions[step_count[0] % len(step_actions)])
             step_count[0] += 1
+            last_obs[0] = obs
             return last
         obs, states, last = env.vmap_sim_ahead(st, actions, env.tau, env.tau)
-        if gatherer is not None:
+        last_obs[0] = obs
+        if gatherer is not None and args.gather == "chunk":
             gatherer.wait()  # previous chunk's gather must have drained before its buffer is reused
-            final = obs[:, -1, :] if obs.ndim == 3 else obs[:, :, -1, :].reshape(B, -1)
-            gathered = gatherer.start(final, gathered)
+            gathered = gatherer.start(final_row(obs), gathered)
         return last
 
     for _ in range(args.warmup):
@@ -217,6 +227,8 @@ def main():
         state = one_step(state)
         ev[k][1].record()
     if gatherer is not None:
+        if args.gather == "end" and last_obs[0] is not None:  # reassemble the global observation batch once
+            gathered = gatherer.start(final_row(last_obs[0]), gathered)
         gatherer.wait()
     torch.cuda.synchronize()
     if world > 1:
@@ -273,7 +285,9 @@ def main():
                             + ("observations only" if args.obs_only else "full outputs (obs + state trajectories)"),
                 "batch_per_gpu": B, "global_batch": B * world, "chunk_steps": Kc, "semantics": args.semantics,
                 "traj_layout": args.traj_layout, "action_layout": args.action_layout,
-                "parallelism": f"batch-sharded x{world}" + (", all-gather(final obs) overlapped" if gatherer else ""),
+                "parallelism": f"batch-sharded x{world}" + (
+                    "" if gatherer is None else (", one all-gather of the final observations at the end" if args.gather == "end"
+                                                 else ", all-gather(final obs) after every chunk, overlapped")),
                 "outputs_finite": finite,
             },
             "roofline": {

@@ -12,5 +12,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 20 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err" || echo "trace run failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/tools/traffic_probe.py" "$@" > "$OUT/pmc_fetch.log" 2>&1 || echo "pmc fetch run failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/tools/traffic_probe.py" "$@" > "$OUT/pmc_write.log" 2>&1 || echo "pmc write run failed"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/pmc_sq" -- python3 "$REPO/tools/traffic_probe.py" "$@" > "$OUT/pmc_sq.log" 2>&1 || echo "pmc sq run failed"
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_sq2" -- python3 "$REPO/tools/traffic_probe.py" "$@" > "$OUT/pmc_sq2.log" 2>&1 || echo "pmc sq2 run failed"
 cd "$REPO"
 find "$OUT" -name "*.csv" | head -20

@@ -87,5 +87,29 @@ if any(pmc.values()):
                        "calibration_write_ratio": calib[1] / gib if calib else None,
                        "source": f"profiles/{tag}_rocprof_summary.md"}
             json.dump(tj, open(tpath, "w"), indent=1, sort_keys=True)
+# ---- SQ counters of the hot kernel (own passes) ----------------------------------------------------
+sq = defaultdict(lambda: defaultdict(float))
+nd = defaultdict(set)
+for sub in ("pmc_sq", "pmc_sq2"):
+    for f in find(sub, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            k = r.get("Kernel_Name", "")
+            if "sim_ahead_kernel" in k or "step_kernel" in k:
+                sq[k][r.get("Counter_Name")] += float(r.get("Counter_Value", 0) or 0)
+                nd[(k, r.get("Counter_Name"))].add(r.get("Dispatch_Id"))
+if sq:
+    lines += ["## SQ counters (per dispatch, summed over the chip)", ""]
+    for k, cs in sq.items():
+        lines += [f"`{k[:100]}`", "", "| counter | value per dispatch |", "|---|---|"]
+        per = {c: v / max(1, len(nd[(k, c)])) for c, v in cs.items()}
+        for c in sorted(per):
+            lines.append(f"| {c} | {per[c]:.4e} |")
+        if "SQ_INSTS_VALU" in per and "SQ_WAVES" in per and per["SQ_WAVES"] > 0:
+            lines.append(f"| VALU wave-instructions per wave | {per['SQ_INSTS_VALU'] / per['SQ_WAVES']:.1f} |")
+        if "SQ_WAIT_ANY" in per and "SQ_WAVE_CYCLES" in per and per["SQ_WAVE_CYCLES"] > 0:
+            lines.append(f"| SQ_WAIT_ANY / SQ_WAVE_CYCLES (wave parked on s_waitcnt) | {per['SQ_WAIT_ANY'] / per['SQ_WAVE_CYCLES']:.3f} |")
+        if "SQ_ACTIVE_INST_VALU" in per and "SQ_WAVE_CYCLES" in per and per["SQ_WAVE_CYCLES"] > 0:
+            lines.append(f"| SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES | {per['SQ_ACTIVE_INST_VALU'] / per['SQ_WAVE_CYCLES']:.3f} |")
+        lines.append("")
 open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
