@@ -37,8 +37,18 @@ WORKLOADS = {
     "pmsm_euler_f32": ("PMSM", "euler", torch.float32, 1e-4, 22, 100),
     "pendulum_euler_f32": ("PENDULUM", "euler", torch.float32, 2e-2, 20, 1000),
     "msd_tsit5_f64": ("MASS_SPRING_DAMPER", "tsit5", torch.float64, 1e-4, 20, 500),
+    # the other environments / solvers at the headline batch (not BASELINE configs; for the per-env table in DESIGN.md)
+    "msd_euler_f32": ("MASS_SPRING_DAMPER", "euler", torch.float32, 1e-4, 22, 100),
+    "cartpole_euler_f32": ("CART_POLE", "euler", torch.float32, 2e-2, 22, 100),
+    "acrobot_euler_f32": ("ACROBOT", "euler", torch.float32, 1e-3, 22, 100),
+    "tank_euler_f32": ("FLUID_TANK", "euler", torch.float32, 1e-3, 22, 100),
+    "pmsm_tsit5_f32": ("PMSM", "tsit5", torch.float32, 1e-4, 22, 100),
+    "pmsm_rk4_f32": ("PMSM", "rk4", torch.float32, 1e-4, 22, 100),
+    "acrobot_tsit5_f32": ("ACROBOT", "tsit5", torch.float32, 1e-3, 22, 100),
+    "pmsm_euler_f64": ("PMSM", "euler", torch.float64, 1e-4, 21, 100),
 }
-ORACLE_NAME = {"PMSM": "pmsm", "PENDULUM": "pendulum", "MASS_SPRING_DAMPER": "mass_spring_damper"}
+ORACLE_NAME = {"PMSM": "pmsm", "PENDULUM": "pendulum", "MASS_SPRING_DAMPER": "mass_spring_damper", "CART_POLE": "cartpole",
+               "ACROBOT": "acrobot", "FLUID_TANK": "fluid_tank"}
 
 
 def build_env(args, device, rank):
@@ -62,6 +72,12 @@ def build_env(args, device, rank):
         ps.omega_el = u(0.0, 600.0)
     elif reg == "PENDULUM":
         ps.theta, ps.omega = u(-np.pi, np.pi), u(-1.0, 1.0)
+    elif reg == "CART_POLE":
+        ps.theta, ps.omega = u(-0.2, 0.2), u(-0.1, 0.1)
+    elif reg == "ACROBOT":
+        ps.theta_1, ps.theta_2 = u(-np.pi, np.pi), u(-1.0, 1.0)
+    elif reg == "FLUID_TANK":
+        ps.height = u(0.5, 2.5)
     g.manual_seed(1237 + rank)
     if args.action_layout == "tiled":
         actions = env.new_actions_buffer(Kc, layout="tiled")
