@@ -79,7 +79,7 @@ template <typename T> __device__ __forceinline__ T wrap_angle(T th) { return pym
 __device__ __forceinline__ void sincos_t(double x, double& s, double& c) { ::sincos(x, &s, &c); }
 
 __device__ __forceinline__ void sincos_t(float x, float& s, float& c) {
-  if (__builtin_expect(!(xabs(x) <= 1024.0f), 0)) {
+  if (__builtin_expect(!(xabs(x) <= 128.0f), 0)) {
     s = ::sinf(x);
     c = ::cosf(x);
     return;
