@@ -182,11 +182,19 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # rehearsal knobs (single-GPU box): EXCENV_BENCH_ONE_GPU=1 puts every rank on GPU 0, EXCENV_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device). The driver's multi-GPU runs use neither.
+    if os.environ.get("EXCENV_BENCH_ONE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("EXCENV_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from exciting_environments_amd import _native
     from exciting_environments_amd.distributed import ObservationGatherer
@@ -200,7 +208,7 @@ def main():
     if use_gather and not dist.is_initialized():  # 1-rank rehearsal of the collective path
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": device} if backend == "nccl" else {}))
     gatherer = ObservationGatherer(B * world) if use_gather else None
     gathered = None
 
@@ -230,6 +238,10 @@ def main():
     for _ in range(args.warmup):
         state = one_step(state)
     if gatherer is not None:
+        # warm the collective up (RCCL sets up its channels / buffers on first use) outside the timed region
+        if last_obs[0] is None:
+            state = one_step(state)
+        gathered = gatherer.start(final_row(last_obs[0]), gathered)
         gatherer.wait()
     torch.cuda.synchronize()
     if world > 1:
