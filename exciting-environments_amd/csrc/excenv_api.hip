@@ -24,19 +24,39 @@ EnvVTable vtable_cartpole();
 EnvVTable vtable_acrobot();
 EnvVTable vtable_tank();
 EnvVTable vtable_pmsm();
+EnvVTable vtable_pmsm_sat();
 
 static const EnvVTable* table(int env) {
-  static const EnvVTable T[EXCENV_NUM_ENVS] = {vtable_pendulum(), vtable_msd(),  vtable_cartpole(),
-                                               vtable_acrobot(),  vtable_tank(), vtable_pmsm()};
-  if (env < 0 || env >= EXCENV_NUM_ENVS) return nullptr;
+  static const EnvVTable T[EXCENV_NUM_ENVS + 1] = {vtable_pendulum(), vtable_msd(),  vtable_cartpole(), vtable_acrobot(),
+                                                   vtable_tank(),     vtable_pmsm(), vtable_pmsm_sat()};
+  if (env < 0 || env > EXCENV_NUM_ENVS) return nullptr;
   return &T[env];
+}
+
+static const EnvVTable* table_public(int env) { return (env >= 0 && env < EXCENV_NUM_ENVS) ? table(env) : nullptr; }
+
+// Launch table for a call: PMSM with LUTs attached runs the saturated model's instantiations.
+static const EnvVTable* table_for(int env, const excenv_props_t* props, int* rc) {
+  *rc = EXCENV_OK;
+  if (env < 0 || env >= EXCENV_NUM_ENVS) return nullptr;
+  if (props && props->pmsm_lut) {
+    const excenv_pmsm_lut_t* l = props->pmsm_lut;
+    if (env != EXCENV_PMSM) { set_error("pmsm_lut is only valid for EXCENV_PMSM"); *rc = EXCENV_EINVAL; return nullptr; }
+    if (l->n_d < 2 || l->n_q < 2 || !l->grid_d || !l->grid_q || !l->tables) {
+      set_error("pmsm_lut: need n_d, n_q >= 2 and non-NULL grid / table pointers");
+      *rc = EXCENV_EINVAL;
+      return nullptr;
+    }
+    return table(EXCENV_NUM_ENVS);
+  }
+  return table(env);
 }
 
 static int g_vec_pref = 0;
 static int g_lds_pad = 0;
 
 static int check_common(const char* fn, int env, int solver, int dtype, int64_t B) {
-  if (!table(env)) { set_error("%s: bad env id %d", fn, env); return EXCENV_EINVAL; }
+  if (env < 0 || env >= EXCENV_NUM_ENVS) { set_error("%s: bad env id %d", fn, env); return EXCENV_EINVAL; }
   if (solver < 0 || solver >= EXCENV_NUM_SOLVERS) { set_error("%s: bad solver id %d", fn, solver); return EXCENV_EINVAL; }
   if (dtype != EXCENV_F32 && dtype != EXCENV_F64) { set_error("%s: bad dtype id %d", fn, dtype); return EXCENV_EINVAL; }
   if (B < 0 || B > ((int64_t)1 << 31) * BLOCK) { set_error("%s: bad batch size %lld", fn, (long long)B); return EXCENV_EINVAL; }
@@ -48,7 +68,7 @@ static int check_control(const char* fn, int env, const excenv_control_t*& c) {
   if (!c) return EXCENV_OK;
   if (c->n_control < 0 || c->n_control > EXCENV_MAX_CONTROL) { set_error("%s: bad n_control %d", fn, c->n_control); return EXCENV_EINVAL; }
   for (int j = 0; j < c->n_control; ++j) {
-    if (c->control_idx[j] < 0 || c->control_idx[j] >= table(env)->S) { set_error("%s: control_idx[%d] out of range", fn, j); return EXCENV_EINVAL; }
+    if (c->control_idx[j] < 0 || c->control_idx[j] >= table_public(env)->S) { set_error("%s: control_idx[%d] out of range", fn, j); return EXCENV_EINVAL; }
     if (!c->reference[j]) { set_error("%s: reference[%d] is NULL", fn, j); return EXCENV_ENULL; }
   }
   return EXCENV_OK;
@@ -65,7 +85,7 @@ int excenv_abi_version(void) { return EXCENV_ABI_VERSION; }
 const char* excenv_last_error(void) { return g_err; }
 
 int excenv_env_dims(int env, int32_t* S, int32_t* A, int32_t* O, int32_t* P) {
-  const EnvVTable* t = table(env);
+  const EnvVTable* t = table_public(env);
   if (!t) { set_error("excenv_env_dims: bad env id %d", env); return EXCENV_EINVAL; }
   if (S) *S = t->S;
   if (A) *A = t->A;
@@ -75,14 +95,14 @@ int excenv_env_dims(int env, int32_t* S, int32_t* A, int32_t* O, int32_t* P) {
 }
 
 int64_t excenv_step_bytes(int env, int dtype) {
-  const EnvVTable* t = table(env);
+  const EnvVTable* t = table_public(env);
   if (!t) return -1;
   const int64_t w = dtype == EXCENV_F64 ? 8 : 4;
   return w * (t->S + t->A + t->S + t->O);
 }
 
 int64_t excenv_sim_ahead_bytes(int env, int dtype, int with_state_traj) {
-  const EnvVTable* t = table(env);
+  const EnvVTable* t = table_public(env);
   if (!t) return -1;
   const int64_t w = dtype == EXCENV_F64 ? 8 : 4;
   return w * (t->A + t->O + (with_state_traj ? t->S : 0));
@@ -104,11 +124,13 @@ int excenv_step(int env, int solver, int dtype, int64_t B, const excenv_props_t*
   if (int rc = check_control("excenv_step", env, control)) return rc;
   StepCall sc{g_vec_pref, solver, dtype, B, props, control, tau, state_in, action, state_out, obs, nullptr, nullptr, nullptr,
               (hipStream_t)stream};
-  return table(env)->step(sc);
+  int rc;
+  const EnvVTable* vt = table_for(env, props, &rc);
+  return vt ? vt->step(sc) : rc;
 }
 
 int32_t excenv_truncated_width(int env, int32_t n_control) {
-  const EnvVTable* t = table(env);
+  const EnvVTable* t = table_public(env);
   if (!t || n_control < 0) return -1;
   return (env == EXCENV_FLUID_TANK || env == EXCENV_PMSM) ? 1 : t->O + n_control;
 }
@@ -125,14 +147,16 @@ int excenv_gym_step(int env, int solver, int dtype, int64_t B, const excenv_prop
   if (int rc = check_control("excenv_gym_step", env, control)) return rc;
   StepCall sc{1, solver, dtype, B, props, control, tau, state_in, action, state_out, obs, reward, terminated, truncated,
               (hipStream_t)stream};
-  return table(env)->step(sc);
+  int rc;
+  const EnvVTable* vt = table_for(env, props, &rc);
+  return vt ? vt->step(sc) : rc;
 }
 
 static inline int64_t align_up(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 int64_t excenv_sim_ahead_workspace_bytes(int env, int dtype, int64_t B, int64_t K, int32_t substeps, int32_t n_control,
                                          int action_layout, int traj_layout, int with_state_traj) {
-  const EnvVTable* t = table(env);
+  const EnvVTable* t = table_public(env);
   if (!t || B < 0 || K < 0 || substeps < 1 || n_control < 0) return -1;
   const int64_t w = dtype == EXCENV_F64 ? 8 : 4, N = K * substeps;
   int64_t bytes = 0;
@@ -167,7 +191,9 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
   }
   if (!props || !state_in || (!actions && K > 0) || !obs_traj || !last_state) { set_error("excenv_sim_ahead: NULL argument"); return EXCENV_ENULL; }
   if (int rc = check_control("excenv_sim_ahead", env, control)) return rc;
-  const EnvVTable* t = table(env);
+  int trc;
+  const EnvVTable* t = table_for(env, props, &trc);
+  if (!t) return trc;
   const int nc = control ? control->n_control : 0;
   const int64_t need = excenv_sim_ahead_workspace_bytes(env, dtype, B, K, substeps, nc, action_layout, traj_layout,
                                                         state_traj != nullptr);

@@ -19,6 +19,11 @@ template <typename T, class M> struct KProps {
   static constexpr int N = M::P + 2 * M::S + 2 * M::A;
   T scalar[N];
   const T* ptr[N];  // per-env [B] array or nullptr
+  // PMSM saturated model: LUT grids / tables (nullptr otherwise)
+  const T* lut_gd;
+  const T* lut_gq;
+  const T* lut_tab;
+  int32_t lut_nd, lut_nq;
 };
 
 template <typename T, class M> struct StepArgs {
@@ -82,6 +87,11 @@ __device__ __forceinline__ void load_ctx(Ctx<T, M>& c, const KProps<T, M>& kp, i
   c.dt = dt;
   c.env_tau = env_tau;
   c.adv_coef = adv_coef;
+  c.lut_gd = kp.lut_gd;
+  c.lut_gq = kp.lut_gq;
+  c.lut_tab = kp.lut_tab;
+  c.lut_nd = kp.lut_nd;
+  c.lut_nq = kp.lut_nq;
 }
 
 // ---- vector access helpers ---------------------------------------------------------------
@@ -220,7 +230,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
       for (int j = 0; j < ka.n_control; ++j) refs[j] = ka.reference[j][i];
       const T rew = env_reward<M, T>(st[0], c, ka.n_control, ka.control_idx, refs);
       ka.reward[i] = rew;
-      if constexpr (M::ID == EXCENV_PMSM) {  // pmsm_env.py:972-983: |i_dq_norm| > 1, terminated == truncated
+      if constexpr (M::IS_PMSM) {  // pmsm_env.py:972-983: |i_dq_norm| > 1, terminated == truncated
         const T nd = normalize(st[0][3], c.smin[3], c.smax[3]), nq = normalize(st[0][4], c.smin[4], c.smax[4]);
         const uint8_t t = xsqrt(nd * nd + nq * nq) > T(1);
         ka.truncated[i] = t;
@@ -268,7 +278,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
     for (int v = 0; v < V; ++v) st[v][j] = tmp[v];
   }
   AheadAux<T> aux[V];
-  if constexpr (AHEAD && M::ID == EXCENV_PMSM) {
+  if constexpr (AHEAD && M::IS_PMSM) {
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       aux[v].eps0 = st[v][2];
@@ -276,7 +286,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
       aux[v].buf0[1] = aux[v].prev_clip[1] = st[v][1];
     }
   }
-  const bool deadtime_on = (M::ID == EXCENV_PMSM) ? (c.P[M::P - 1] > T(0)) : false;
+  const bool deadtime_on = (M::IS_PMSM) ? (c.P[M::P - 1] > T(0)) : false;
 
   const int64_t N = ka.K * ka.substeps;
   // V > 1 implies env stride 1; for V == 1 the host has checked that 256 * stride * sizeof(T) < 2^31
@@ -319,7 +329,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
       for (int j = 0; j < S; ++j) sv[v][j] = st[v][j];
       if constexpr (AHEAD) {
         M::post(sv[v], c);
-        if constexpr (M::ID == EXCENV_PMSM) {  // pmsm_env.py:785-791
+        if constexpr (M::IS_PMSM) {  // pmsm_env.py:785-791
           if (deadtime_on) {
             sv[v][0] = (n == 0) ? aux[v].buf0[0] : aux[v].prev_clip[0];
             sv[v][1] = (n == 0) ? aux[v].buf0[1] : aux[v].prev_clip[1];

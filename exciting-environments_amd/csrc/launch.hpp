@@ -68,6 +68,15 @@ static bool fill_props(KProps<T, M>& kp, const excenv_props_t* p) {
   for (int j = 0; j < M::S; ++j) put(p->state_max[j]);
   for (int j = 0; j < M::A; ++j) put(p->action_min[j]);
   for (int j = 0; j < M::A; ++j) put(p->action_max[j]);
+  kp.lut_gd = kp.lut_gq = kp.lut_tab = nullptr;
+  kp.lut_nd = kp.lut_nq = 0;
+  if (p->pmsm_lut) {
+    kp.lut_gd = (const T*)p->pmsm_lut->grid_d;
+    kp.lut_gq = (const T*)p->pmsm_lut->grid_q;
+    kp.lut_tab = (const T*)p->pmsm_lut->tables;
+    kp.lut_nd = p->pmsm_lut->n_d;
+    kp.lut_nq = p->pmsm_lut->n_q;
+  }
   return batched;
 }
 
@@ -86,7 +95,7 @@ static inline int check_launch(const char* what) {
 // reference's state, pmsm_env.py:866-875); returns the double-folded (deadtime + 0.5) * tau.
 template <class M> static int pmsm_coef(const excenv_props_t* p, double env_tau, double* coef) {
   *coef = 0.0;
-  if constexpr (M::ID == EXCENV_PMSM) {
+  if constexpr (M::IS_PMSM) {
     const excenv_param_t& d = p->static_params[6];
     if (d.per_env) {
       set_error("PMSM: static_params.deadtime must be a scalar, not a per-env array");
@@ -183,7 +192,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   const bool batched = fill_props<T, M>(ka.kp, sc.props);
   double coef;
   if (int rc = pmsm_coef<M>(sc.props, sc.env_tau, &coef)) return rc;
-  if (M::ID == EXCENV_PMSM && sc.substeps != 1) {
+  if (M::IS_PMSM && sc.substeps != 1) {
     set_error("PMSM: obs_stepsize must equal action_stepsize (reference pmsm_env.py:787)");
     return EXCENV_EUNSUPPORTED;
   }

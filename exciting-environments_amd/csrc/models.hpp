@@ -14,11 +14,17 @@ template <typename T, class M> struct Ctx {
   T dt;        // solver step (obs_stepsize; == tau on the step path)
   T env_tau;   // self.tau (PMSM angle prediction)
   T adv_coef;  // PMSM: (deadtime + 0.5) * tau, folded in double on the host (pmsm_env.py:599-604)
+  // PMSM saturated model only: LUT grids and the node-interleaved tables [n_d][n_q][8]
+  const T* lut_gd;
+  const T* lut_gq;
+  const T* lut_tab;
+  int lut_nd, lut_nq;
 };
 
 // ---- Pendulum: pendulum_env.py:144-150,188 ; P = (g,l,m) --------------------------------
 template <typename T> struct Pendulum {
   static constexpr int ID = EXCENV_PENDULUM, S = 2, A = 1, O = 2, P = 3, NY = 2;
+  static constexpr bool IS_PMSM = false;
   using C = Ctx<T, Pendulum>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; y[1] = st[1]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; st[1] = y[1]; }
@@ -37,6 +43,7 @@ template <typename T> struct Pendulum {
 // ---- MassSpringDamper: mass_spring_damper_env.py:142-148 ; P = (d,k,m) ---------------------
 template <typename T> struct MassSpringDamper {
   static constexpr int ID = EXCENV_MASS_SPRING_DAMPER, S = 2, A = 1, O = 2, P = 3, NY = 2;
+  static constexpr bool IS_PMSM = false;
   using C = Ctx<T, MassSpringDamper>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; y[1] = st[1]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; st[1] = y[1]; }
@@ -55,6 +62,7 @@ template <typename T> struct MassSpringDamper {
 // ---- CartPole: cart_pole_env.py:159-180,229 ; P = (mu_p,mu_c,l,m_p,m_c,g) -----------------
 template <typename T> struct CartPole {
   static constexpr int ID = EXCENV_CART_POLE, S = 4, A = 1, O = 4, P = 6, NY = 4;
+  static constexpr bool IS_PMSM = false;
   using C = Ctx<T, CartPole>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) {
 #pragma unroll
@@ -90,6 +98,7 @@ template <typename T> struct CartPole {
 // ---- Acrobot: acrobot_env.py:171-197,247-248 ; P = (g,l_1,l_2,m_1,m_2,l_c1,l_c2,I_1,I_2) ----
 template <typename T> struct Acrobot {
   static constexpr int ID = EXCENV_ACROBOT, S = 4, A = 1, O = 4, P = 9, NY = 4;
+  static constexpr bool IS_PMSM = false;
   using C = Ctx<T, Acrobot>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) {
 #pragma unroll
@@ -133,6 +142,7 @@ template <typename T> struct Acrobot {
 // ---- FluidTank: fluid_tank_env.py:97-106,146 ; P = (base_area, orifice_area, c_d, g) ---------
 template <typename T> struct FluidTank {
   static constexpr int ID = EXCENV_FLUID_TANK, S = 1, A = 1, O = 1, P = 4, NY = 1;
+  static constexpr bool IS_PMSM = false;
   using C = Ctx<T, FluidTank>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; }
@@ -151,6 +161,7 @@ template <typename T> struct FluidTank {
 //      state = (u_d_buffer,u_q_buffer,epsilon,i_d,i_q,torque,omega_el) ; y = (i_d,i_q,eps)
 template <typename T> struct Pmsm {
   static constexpr int ID = EXCENV_PMSM, S = 7, A = 2, O = 8, P = 7, NY = 3;
+  static constexpr bool IS_PMSM = true;
   using C = Ctx<T, Pmsm>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[3]; y[1] = st[4]; y[2] = st[2]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[3] = y[0]; st[4] = y[1]; st[2] = y[2]; }
@@ -172,7 +183,7 @@ template <typename T> struct Pmsm {
     st[5] = torque(st[3], st[4], c);
   }
   // pmsm_env.py:898-919: [i_d, i_q, omega_el, torque, cos eps, sin eps, u_d_buffer, u_q_buffer]
-  __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
+  template <class CC> __device__ static __forceinline__ void observe(const T (&st)[S], const CC& c, T (&ob)[O]) {
     T sn, cs;
     sincos_t(st[2], sn, cs);
     ob[0] = normalize(st[3], c.smin[3], c.smax[3]);
@@ -214,7 +225,8 @@ template <typename T> struct Pmsm {
   }
 
   // pmsm_env.py:594-616 constraint_denormalization with the angle `eps` as given
-  __device__ static __forceinline__ void constraint(const T (&a)[A], T eps, T omega_el, const C& c, T (&uc)[2]) {
+  template <class CC>
+  __device__ static __forceinline__ void constraint(const T (&a)[A], T eps, T omega_el, const CC& c, T (&uc)[2]) {
     const T u_dc = c.P[5];
     const T half_dc = u_dc / T(2);
     const T u_d = denormalize(a[0], c.amin[0], c.amax[0]);
@@ -234,6 +246,75 @@ template <typename T> struct Pmsm {
     const T o_q = (-sn) * al + cs * be;
     uc[0] = o_d * half_dc;
     uc[1] = o_q * half_dc;
+  }
+};
+
+// ---- PMSM saturated model: nonlinear_ode (pmsm_env.py:487-507), currents_to_torque_saturated (:377-381) -----------
+// Everything else (action path, dead time, observation) is the linear model's.
+template <typename T> struct PmsmSat {
+  static constexpr int ID = EXCENV_PMSM, S = 7, A = 2, O = 8, P = 7, NY = 3;
+  static constexpr bool IS_PMSM = true;
+  using C = Ctx<T, PmsmSat>;
+  using L = Pmsm<T>;
+  __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[3]; y[1] = st[4]; y[2] = st[2]; }
+  __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[3] = y[0]; st[4] = y[1]; st[2] = y[2]; }
+
+  // jax.scipy.interpolate.RegularGridInterpolator._find_indices: i = clip(searchsorted(g, x) - 1, 0, n - 2),
+  // t = (x - g[i]) / (g[i+1] - g[i])  (not clipped: linear extrapolation; the padded edge makes it constant)
+  __device__ static __forceinline__ void find(const T* g, int n, T x, int& i, T& t) {
+    int lo = 0, hi = n;
+    while (lo < hi) {  // first index with g[idx] >= x
+      const int mid = (lo + hi) >> 1;
+      if (g[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    i = lo - 1;
+    i = (i < 0) ? 0 : i;
+    i = (i > n - 2) ? n - 2 : i;
+    t = (x - g[i]) / (g[i + 1] - g[i]);
+  }
+  // six bilinear look-ups sharing one cell: _evaluate_linear's corner order (i,j), (i,j+1), (i+1,j), (i+1,j+1)
+  __device__ static __forceinline__ void lookup(T i_d, T i_q, const C& c, T (&q)[6]) {
+    int ix, iy;
+    T tx, ty;
+    find(c.lut_gd, c.lut_nd, i_d, ix, tx);
+    find(c.lut_gq, c.lut_nq, i_q, iy, ty);
+    const T w00 = (T(1) - tx) * (T(1) - ty), w01 = (T(1) - tx) * ty, w10 = tx * (T(1) - ty), w11 = tx * ty;
+    const T* n00 = c.lut_tab + ((int64_t)ix * c.lut_nq + iy) * 8;
+    const T* n10 = n00 + (int64_t)c.lut_nq * 8;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q[k] = T(0) + n00[k] * w00 + n00[8 + k] * w01 + n10[k] * w10 + n10[8 + k] * w11;
+  }
+  __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&st)[S], T (&dy)[NY]) {
+    const T r_s = c.P[1], omega_el = st[6];
+    T q[6];
+    lookup(y[0], y[1], c, q);
+    const T L_dd = q[0], L_dq = q[1], L_qd = q[2], L_qq = q[3], Psi_d = q[4], Psi_q = q[5];
+    // 2x2 inverse in closed form (the reference calls jnp.linalg.inv: LU; parity of this model is unpinned anyway)
+    const T det = L_dd * L_qq - L_dq * L_qd;
+    const T a00 = L_qq / det, a01 = -L_dq / det, a10 = -L_qd / det, a11 = L_dd / det;
+    const T j0 = -Psi_q, j1 = Psi_d;  // J_k @ psi_dq, J_k = [[0,-1],[1,0]]
+    const T d1_0 = (-a00 * r_s) * y[0] + (-a01 * r_s) * y[1];
+    const T d1_1 = (-a10 * r_s) * y[0] + (-a11 * r_s) * y[1];
+    const T d2_0 = a00 * u[0] + a01 * u[1];
+    const T d2_1 = a10 * u[0] + a11 * u[1];
+    const T d3_0 = ((-a00) * j0 + (-a01) * j1) * omega_el;
+    const T d3_1 = ((-a10) * j0 + (-a11) * j1) * omega_el;
+    dy[0] = d1_0 + d2_0 + d3_0;
+    dy[1] = d1_1 + d2_1 + d3_1;
+    dy[2] = omega_el;
+  }
+  __device__ static __forceinline__ T torque(T i_d, T i_q, const C& c) {
+    T q[6];
+    lookup(i_d, i_q, c, q);
+    return T(1.5) * c.P[0] * (q[4] * i_q - q[5] * i_d);
+  }
+  __device__ static __forceinline__ void post(T (&st)[S], const C& c) {
+    st[2] = wrap_angle(st[2]);
+    st[5] = torque(st[3], st[4], c);
+  }
+  __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) { L::observe(st, c, ob); }
+  __device__ static __forceinline__ void constraint(const T (&a)[A], T eps, T omega_el, const C& c, T (&uc)[2]) {
+    L::constraint(a, eps, omega_el, c, uc);
   }
 };
 
@@ -264,7 +345,7 @@ __device__ __forceinline__ void pick_field(const T (&st)[M::S], const Ctx<T, M>&
 template <class M, typename T>
 __device__ __forceinline__ T env_reward(const T (&st)[M::S], const Ctx<T, M>& c, int n_control, const int* idx, const T* ref) {
   T reward = T(0);
-  if constexpr (M::ID == EXCENV_PMSM) {
+  if constexpr (M::IS_PMSM) {
     // control_state membership: "i_d" (3), "i_q" (4), "torque" (5)
     T r_id = T(0), r_iq = T(0), r_tq = T(0);
     bool has_id = false, has_iq = false, has_tq = false;

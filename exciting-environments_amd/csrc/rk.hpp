@@ -93,7 +93,7 @@ __device__ __forceinline__ void rk_step(T (&y)[M::NY], const T (&u)[M::A], const
 template <class M, int SOLVER, typename T>
 __device__ __forceinline__ void env_step(T (&st)[M::S], const T (&a)[M::A], const Ctx<T, M>& c) {
   T u[M::A];
-  if constexpr (M::ID == EXCENV_PMSM) {
+  if constexpr (M::IS_PMSM) {
     T uc[2];
     M::constraint(a, st[2], st[6], c, uc);
     if (c.P[6] > T(0)) {  // deadtime: apply the buffered voltage, buffer the new one
@@ -124,7 +124,7 @@ template <class M, int SOLVER, typename T>
 __device__ __forceinline__ void env_advance_raw(T (&st)[M::S], const T (&a)[M::A], const T (&a1)[M::A], int64_t k,
                                                 int64_t k1, const Ctx<T, M>& c, AheadAux<T>& aux) {
   T u[M::A], u1[M::A];
-  if constexpr (M::ID == EXCENV_PMSM) {
+  if constexpr (M::IS_PMSM) {
     T uc[2];
     M::constraint(a, aux.eps0 + (T(k) * c.env_tau) * st[6], st[6], c, uc);
     if (c.P[6] > T(0)) {

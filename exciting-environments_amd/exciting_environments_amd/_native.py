@@ -26,6 +26,11 @@ class Param(ctypes.Structure):
     _fields_ = [("value", ctypes.c_double), ("per_env", ctypes.c_void_p)]
 
 
+class PmsmLut(ctypes.Structure):
+    _fields_ = [("n_d", ctypes.c_int32), ("n_q", ctypes.c_int32), ("grid_d", ctypes.c_void_p),
+                ("grid_q", ctypes.c_void_p), ("tables", ctypes.c_void_p)]
+
+
 class Props(ctypes.Structure):
     _fields_ = [
         ("static_params", Param * MAX_STATIC),
@@ -33,6 +38,7 @@ class Props(ctypes.Structure):
         ("state_max", Param * MAX_STATE),
         ("action_min", Param * MAX_ACTION),
         ("action_max", Param * MAX_ACTION),
+        ("pmsm_lut", ctypes.POINTER(PmsmLut)),
     ]
 
 
@@ -71,7 +77,7 @@ def lib():
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
                    "excenv_probe_math", "excenv_set_tuning"):
             getattr(l, fn).restype = ctypes.c_int
-        if l.excenv_abi_version() != 1:
+        if l.excenv_abi_version() != 2:
             raise ImportError("libexcenv_hip.so: ABI version mismatch")
         _lib = l
     return _lib

@@ -10,9 +10,12 @@ from dataclasses import dataclass, make_dataclass, replace
 from enum import Enum
 from typing import Any, Callable
 
+import ctypes
+
 import numpy as np
 import torch
 
+from . import _native
 from .core_env import CoreEnvironment
 from .solvers import Euler
 from .utils import MinMaxNormalization
@@ -222,9 +225,46 @@ def _motor_params(variant: MotorVariant) -> MotorParams:
     return MotorParams(pn, an, sp)
 
 
+SATURATED_QUANTS = ("L_dd", "L_dq", "L_qd", "L_qq", "Psi_d", "Psi_q")
+
+
+def prepare_pmsm_lut(pmsm_lut: dict):
+    """Mirror of PMSM.generate_interpolators_and_lut (pmsm_env.py:316-363): NaNs of every table are filled from the nearest
+    valid node, every edge is repeated once (so that linear extrapolation is constant), and the grids are extended by one
+    step on each side. `pmsm_lut` has the reference's keys: i_d_vec, i_q_vec (shape (1, n) or (n,)) and the six tables
+    L_dd, L_dq, L_qd, L_qq, Psi_d, Psi_q of shape (n_iq, n_id). Returns (grid_d [n_d], grid_q [n_q], tables [n_d, n_q, 8])
+    as float64 numpy arrays; tables[ix, iy, k] is quantity k at (grid_d[ix], grid_q[iy])."""
+    from scipy.interpolate import griddata
+
+    i_d_vec = np.asarray(pmsm_lut["i_d_vec"], dtype=np.float64).reshape(1, -1)
+    i_q_vec = np.asarray(pmsm_lut["i_q_vec"], dtype=np.float64).reshape(1, -1)
+    i_d_max, i_q_max, i_d_min, i_q_min = i_d_vec.max(), i_q_vec.max(), i_d_vec.min(), i_q_vec.min()
+    i_d_stepsize = (i_d_max - i_d_min) / (i_d_vec.shape[1] - 1)
+    i_q_stepsize = (i_q_max - i_q_min) / (i_q_vec.shape[1] - 1)
+    padded = {}
+    for q in SATURATED_QUANTS:
+        qmap = np.array(pmsm_lut[q], dtype=np.float64, copy=True)
+        x, y = np.indices(qmap.shape)
+        nan_mask = np.isnan(qmap)
+        if nan_mask.any():
+            qmap[nan_mask] = griddata((x[~nan_mask], y[~nan_mask]), qmap[~nan_mask], (x[nan_mask], y[nan_mask]), method="nearest")
+        a = np.vstack([qmap[0, :], qmap, qmap[-1, :]])
+        padded[q] = np.hstack([a[:, :1], a, a[:, -1:]])
+    n_y, n_x = padded[SATURATED_QUANTS[0]].shape
+    grid_d = np.linspace(i_d_min - i_d_stepsize, i_d_max + i_d_stepsize, n_x)
+    grid_q = np.linspace(i_q_min - i_q_stepsize, i_q_max + i_q_stepsize, n_y)
+    tables = np.zeros((n_x, n_y, 8), dtype=np.float64)
+    for k, q in enumerate(SATURATED_QUANTS):
+        tables[:, :, k] = padded[q].T
+    return grid_d, grid_q, tables
+
+
 class PMSM(CoreEnvironment):
-    """Permanent-magnet synchronous motor, linear dq-frame model with voltage-hexagon clip and one-step action
-    dead time (pmsm/pmsm_env.py:115-267). ``saturated=True`` (LUT model) is out of the hot-path scope."""
+    """Permanent-magnet synchronous motor in dq coordinates with voltage-hexagon clip and one-step action dead time
+    (pmsm/pmsm_env.py:115-267). ``saturated=False``: linear model (`linear_ode`). ``saturated=True``: flux linkages and
+    differential inductances from look-up tables (`nonlinear_ode`); pass the tables as ``pmsm_lut=`` (a dict with the
+    reference's keys, e.g. ``scipy.io.loadmat`` of the reference's LUT file) — the motor data files themselves are not
+    redistributed here."""
 
     ENV_ID = 5
     STATE_FIELDS = ("u_d_buffer", "u_q_buffer", "epsilon", "i_d", "i_q", "torque", "omega_el")
@@ -247,16 +287,25 @@ class PMSM(CoreEnvironment):
     def __init__(self, batch_size: int = 8, saturated=False, motor_variant: MotorVariant = MotorVariant.DEFAULT,
                  physical_normalizations: dict = None, action_normalizations: dict = None,
                  soft_constraints: Callable = None, static_params: dict = None, control_state: list = None,
-                 solver=Euler(), tau: float = 1e-4, dtype=torch.float32, device=None):
+                 solver=Euler(), tau: float = 1e-4, dtype=torch.float32, device=None, pmsm_lut: dict = None):
+        self._lut_host = None
+        motor_params = motor_variant.get_params()
         if saturated:
             if motor_variant == MotorVariant.DEFAULT:
                 raise ValueError(
                     f"MotorVariant '{motor_variant.value}' is not allowed for saturated LUTs. "
                     "Use a specific motor variant. DEFAULT is only valid for saturated=False."
                 )
-            raise NotImplementedError("PMSM(saturated=True): the LUT model is outside the accelerated hot path "
-                                      "(SURVEY.md §2, §8f rank 3)")
-        motor_params = motor_variant.get_params()
+            if pmsm_lut is None:
+                raise ValueError(
+                    "PMSM(saturated=True) needs the look-up tables: pass pmsm_lut=<dict with i_d_vec, i_q_vec, L_dd, L_dq, "
+                    "L_qd, L_qq, Psi_d, Psi_q>, e.g. scipy.io.loadmat of the reference's LUT_<motor>_jax_grad.mat "
+                    "(the motor data files are not redistributed with this package)."
+                )
+            self._lut_host = prepare_pmsm_lut(pmsm_lut)
+            self.pmsm_lut = pmsm_lut
+            for k in ("l_d", "l_q", "psi_p"):  # pmsm_env.py:171-174
+                motor_params.static_params[k] = float("nan")
         if not static_params:
             static_params = motor_params.static_params
         if not physical_normalizations:
@@ -276,6 +325,29 @@ class PMSM(CoreEnvironment):
         super().__init__(batch_size, env_properties=env_properties, tau=tau, solver=solver, dtype=dtype, device=device)
         self._action_description = ["u_d", "u_q"]
         self._obs_description = ["i_d", "i_q", "cos_eps", "sin_eps", "omega_el", "torque", "u_d_buffer", "u_q_buffer"]
+
+    def _pack_props(self, env_properties, B: int):
+        p, keep = super()._pack_props(env_properties, B)
+        if getattr(env_properties, "saturated", False):
+            gd, gq, tab = (torch.as_tensor(a, dtype=self.dtype, device=self.device).contiguous() for a in self._lut_host)
+            lut = _native.PmsmLut(gd.shape[0], gq.shape[0], gd.data_ptr(), gq.data_ptr(), tab.data_ptr())
+            keep += [gd, gq, tab, lut]
+            p.pmsm_lut = ctypes.pointer(lut)
+        return p, keep
+
+    def _lut_torch(self, i_d, i_q):
+        """Bilinear look-up of the six quantities with torch ops (random reset only; the kernels carry their own)."""
+        gd, gq, tab = (torch.as_tensor(a, dtype=self.dtype, device=self.device) for a in self._lut_host)
+
+        def find(g, x):
+            i = (torch.searchsorted(g, x.contiguous()) - 1).clamp(0, g.numel() - 2)
+            return i, (x - g[i]) / (g[i + 1] - g[i])
+
+        ix, tx = find(gd, i_d)
+        iy, ty = find(gq, i_q)
+        w = lambda a, b: (a * b)[..., None]
+        return (tab[ix, iy] * w(1 - tx, 1 - ty) + tab[ix, iy + 1] * w(1 - tx, ty) + tab[ix + 1, iy] * w(tx, 1 - ty)
+                + tab[ix + 1, iy + 1] * w(tx, ty))
 
     def create_in_axes_dataclass(self, dataclass_obj):
         if isinstance(dataclass_obj, PMSM.EnvProperties):  # `saturated` is a plain bool leaf
@@ -309,7 +381,11 @@ class PMSM(CoreEnvironment):
             i_q = i_q - 2 * relu(i_q - q_hi) + 2 * relu(-i_q + q_lo)
             sp = env_properties.static_params
             leaf = self._norm_leaf
-            torque = 1.5 * leaf(sp.p) * (leaf(sp.psi_p) + (leaf(sp.l_d) - leaf(sp.l_q)) * i_d) * i_q
+            if getattr(env_properties, "saturated", False):  # currents_to_torque_saturated (pmsm_env.py:377-381)
+                q = self._lut_torch(i_d, i_q)
+                torque = 1.5 * leaf(sp.p) * (q[..., 4] * i_q - q[..., 5] * i_d)
+            else:
+                torque = 1.5 * leaf(sp.p) * (leaf(sp.psi_p) + (leaf(sp.l_d) - leaf(sp.l_q)) * i_d) * i_q
             (e_lo, e_hi), (o_lo, o_hi) = lo_hi("epsilon"), lo_hi("omega_el")
             phys = dict(u_d_buffer=full(0.0), u_q_buffer=full(0.0),
                         epsilon=(state_norm[0] + 1) / 2 * (e_hi - e_lo) + e_lo, i_d=i_d, i_q=i_q, torque=torque,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXCENV_ABI_VERSION 1
+#define EXCENV_ABI_VERSION 2
 
 /* Environment ids. Field orders follow the reference dataclasses. */
 typedef enum {
@@ -81,14 +81,29 @@ typedef struct {
   const void* per_env;
 } excenv_param_t;
 
+/* PMSM saturated model (pmsm_env.py:316-363, 487-507): the six look-up tables of the flux linkages / differential
+ * inductances over the (i_d, i_q) grid, prepared as the reference's generate_interpolators_and_lut does (NaNs filled
+ * by nearest neighbour, edges repeated once). All arrays are device arrays of the working dtype.
+ *   grid_d [n_d], grid_q [n_q] : strictly increasing grid coordinates
+ *   tables [n_d][n_q][8]       : (L_dd, L_dq, L_qd, L_qq, Psi_d, Psi_q, 0, 0) at each grid node */
+typedef struct {
+  int32_t n_d, n_q;
+  const void* grid_d;
+  const void* grid_q;
+  const void* tables;
+} excenv_pmsm_lut_t;
+
 /* EnvProperties (core_env.py:245-251): static params in the field order listed at the env id,
- * min/max of physical_normalizations per state field and of action_normalizations per action. */
+ * min/max of physical_normalizations per state field and of action_normalizations per action.
+ * pmsm_lut: NULL, or (EXCENV_PMSM only) the LUTs of the saturated model — selects nonlinear_ode /
+ * currents_to_torque_saturated instead of the linear dq model (EnvProperties.saturated, pmsm_env.py:307-314). */
 typedef struct {
   excenv_param_t static_params[EXCENV_MAX_STATIC];
   excenv_param_t state_min[EXCENV_MAX_STATE];
   excenv_param_t state_max[EXCENV_MAX_STATE];
   excenv_param_t action_min[EXCENV_MAX_ACTION];
   excenv_param_t action_max[EXCENV_MAX_ACTION];
+  const excenv_pmsm_lut_t* pmsm_lut;
 } excenv_props_t;
 
 /* Reference-tracking columns of the observation (generate_observation appends the normalised

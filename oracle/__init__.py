@@ -63,6 +63,11 @@ class Param(ctypes.Structure):
     _fields_ = [("value", ctypes.c_double), ("per_env", ctypes.c_void_p)]
 
 
+class PmsmLut(ctypes.Structure):
+    _fields_ = [("n_d", ctypes.c_int32), ("n_q", ctypes.c_int32), ("grid_d", ctypes.c_void_p),
+                ("grid_q", ctypes.c_void_p), ("tables", ctypes.c_void_p)]
+
+
 class Props(ctypes.Structure):
     _fields_ = [
         ("static_params", Param * MAX_STATIC),
@@ -70,6 +75,7 @@ class Props(ctypes.Structure):
         ("state_max", Param * MAX_STATE),
         ("action_min", Param * MAX_ACTION),
         ("action_max", Param * MAX_ACTION),
+        ("pmsm_lut", ctypes.POINTER(PmsmLut)),
     ]
 
 
@@ -126,11 +132,18 @@ def _fill(param: Param, v, dtype, B, keep):
         param.per_env = None
 
 
-def make_props(env: str, params: dict, phys_norm: dict, act_norm: dict, dtype, B: int):
-    """params: name->scalar|[B]; phys_norm/act_norm: name->(min,max) each scalar|[B]. Returns (Props, keepalive)."""
+def make_props(env: str, params: dict, phys_norm: dict, act_norm: dict, dtype, B: int, pmsm_lut=None):
+    """params: name->scalar|[B]; phys_norm/act_norm: name->(min,max) each scalar|[B]. Returns (Props, keepalive).
+    pmsm_lut: (grid_d [n_d], grid_q [n_q], tables [n_d, n_q, 8]) host arrays for the PMSM saturated model."""
     dtype = np.dtype(dtype)
     keep: list = []
     p = Props()
+    if pmsm_lut is not None:
+        gd, gq, tab = (np.ascontiguousarray(a, dtype=dtype) for a in pmsm_lut)
+        assert tab.shape == (gd.shape[0], gq.shape[0], 8)
+        lut = PmsmLut(gd.shape[0], gq.shape[0], gd.ctypes.data, gq.ctypes.data, tab.ctypes.data)
+        keep += [gd, gq, tab, lut]
+        p.pmsm_lut = ctypes.pointer(lut)
     for j, name in enumerate(PARAM_FIELDS[env]):
         _fill(p.static_params[j], params[name], dtype, B, keep)
     for j, name in enumerate(STATE_FIELDS[env]):

@@ -128,6 +128,7 @@ int oracle_step(int env, int solver, int dtype, int64_t B, const excenv_props_t*
   int rc = check_common(env, solver, dtype, B);
   if (rc) return rc;
   if (!props || !state_in || !action || !state_out || !obs) return EXCENV_ENULL;
+  if (props->pmsm_lut && env != EXCENV_PMSM) return EXCENV_EINVAL;
   if (control && control->n_control == 0) control = NULL;
   return dtype == EXCENV_F32
              ? oracle_step_f32(&ENVS[env], solver, B, props, control, tau, state_in, action, state_out, obs)

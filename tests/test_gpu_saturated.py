@@ -1,0 +1,93 @@
+"""PMSM saturated (LUT) model on the GPU: HIP kernels vs the CPU oracle on a saturating machine with
+NaN holes in the tables, and vs the linear-model kernels when the tables encode the linear motor. ``-m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import NP_DTYPE, random_state, spec_of, to_state
+from helpers_lut import linear_lut, saturating_lut
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(B, dtype, solver, lut, control_state=None):
+    import exciting_environments_amd as ex
+    from exciting_environments_amd import EnvironmentRegistry, MotorVariant, prepare_pmsm_lut
+
+    solv = {"euler": ex.Euler(), "rk4": ex.RK4(), "tsit5": ex.Tsit5()}[solver]
+    env = EnvironmentRegistry.PMSM.make(batch_size=B, saturated=True, motor_variant=MotorVariant.BRUSA, pmsm_lut=lut, solver=solv,
+                                        dtype=dtype, device="cuda", control_state=control_state)
+    ep = env.env_properties
+    params = {n: getattr(ep.static_params, n) for n in env.PARAM_FIELDS}
+    pn = {n: (getattr(ep.physical_normalizations, n).min, getattr(ep.physical_normalizations, n).max) for n in env.STATE_FIELDS}
+    an = {n: (getattr(ep.action_normalizations, n).min, getattr(ep.action_normalizations, n).max) for n in env.ACTION_FIELDS}
+    props, keep = oracle.make_props("pmsm", params, pn, an, NP_DTYPE[dtype], B, pmsm_lut=prepare_pmsm_lut(lut))
+    spec = dict(params=params, phys_norm=pn, act_norm=an, tau=env.tau)
+    return env, props, keep, spec
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("solver", ["euler", "rk4", "tsit5"])
+def test_saturated_step_and_sim_ahead_match_oracle(solver, dtype):
+    # the synthetic machine is Euler-unstable at these speeds (errors double every few steps): fp32 is compared on a short
+    # horizon, fp64 on the long one (kernel and oracle agree to 1e-12 there, so the arithmetic is the same)
+    B, K = 2048, (48 if dtype == torch.float64 else 10)
+    env, props, keep, spec = _make(B, dtype, solver, saturating_lut())
+    st = random_state("pmsm", B, NP_DTYPE[dtype], spec, seed=401)
+    st[3][::5] = -400.0  # beyond the table: constant extrapolation through the padded edge
+    rng = np.random.default_rng(402)
+    acts = rng.uniform(-1, 1, (B, K, 2)).astype(NP_DTYPE[dtype])
+    tol = 1e-9 if dtype == torch.float64 else 5e-5
+    obs, new = env.vmap_step(to_state(env, st), torch.as_tensor(acts[:, 0], device=env.device))
+    o_ref, s_ref = oracle.step("pmsm", solver, st, acts[:, 0], props, spec["tau"])
+    assert np.allclose(obs.cpu().numpy(), o_ref, rtol=tol, atol=tol)
+    assert np.allclose(new.physical_state.torque.cpu().numpy(), s_ref[5], rtol=tol, atol=tol * 200)
+    for sem, osem in (("step", oracle.SEM_STEP), ("ahead", oracle.SEM_AHEAD)):
+        env.sim_ahead_semantics = sem
+        a_dev = env.new_actions_buffer(K)
+        a_dev.copy_(torch.as_tensor(acts, device=env.device))
+        o, s, l = env.vmap_sim_ahead(to_state(env, st), a_dev, env.tau, env.tau)
+        o_ref, s_ref, l_ref = oracle.sim_ahead("pmsm", solver, st, acts, props, spec["tau"], semantics=osem)
+        assert np.allclose(o.cpu().numpy(), o_ref, rtol=tol, atol=tol), (sem, float(np.abs(o.cpu().numpy() - o_ref).max()))
+        assert np.allclose(s.physical_state.i_q.cpu().numpy(), s_ref[4], rtol=tol, atol=tol * 250)
+
+
+def test_linear_tables_reproduce_the_linear_kernels():
+    """Tables that encode the linear BRUSA motor: the saturated kernels agree with the linear-model kernels."""
+    from exciting_environments_amd import EnvironmentRegistry, MotorVariant
+
+    B, K = 1024, 64
+    sp = MotorVariant.BRUSA.get_params().static_params
+    lut = linear_lut(sp["l_d"], sp["l_q"], sp["psi_p"], i_d_range=(-2000, 2000), i_q_range=(-2000, 2000), n_d=81, n_q=81)
+    env_s, props, keep, spec = _make(B, torch.float64, "tsit5", lut)
+    import exciting_environments_amd as ex
+    env_l = EnvironmentRegistry.PMSM.make(batch_size=B, motor_variant=MotorVariant.BRUSA, solver=ex.Tsit5(), dtype=torch.float64, device="cuda")
+    st = random_state("pmsm", B, np.float64, spec, seed=411)
+    acts = torch.as_tensor(np.random.default_rng(412).uniform(-1, 1, (B, K, 2)), device="cuda")
+    o_s, s_s, _ = env_s.vmap_sim_ahead(to_state(env_s, st), acts, env_s.tau, env_s.tau)
+    o_l, s_l, _ = env_l.vmap_sim_ahead(to_state(env_l, st), acts, env_l.tau, env_l.tau)
+    assert torch.allclose(o_s, o_l, rtol=1e-9, atol=1e-9)
+    assert torch.allclose(s_s.physical_state.torque, s_l.physical_state.torque, rtol=1e-9, atol=1e-7)
+
+
+def test_saturated_gym_step_and_layouts():
+    B, K = 1024, 9
+    env, props, keep, spec = _make(B, torch.float32, "euler", saturating_lut(), control_state=["i_d", "i_q", "torque"])
+    st = random_state("pmsm", B, np.float32, spec, seed=421)
+    rng = np.random.default_rng(422)
+    refs = {"i_d": rng.uniform(-200, -20, B).astype(np.float32), "i_q": rng.uniform(-200, 200, B).astype(np.float32),
+            "torque": rng.uniform(-150, 150, B).astype(np.float32)}
+    act = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+    state = to_state(env, st, reference=refs)
+    obs, reward, term, trunc, new = env.vmap_gym_step(state, torch.as_tensor(act, device=env.device))
+    o_ref, s_ref, r_ref, te_ref, tr_ref = oracle.gym_step("pmsm", "euler", st, act, props, spec["tau"],
+                                                          control=[(n, refs[n]) for n in ("i_d", "i_q", "torque")])
+    assert np.allclose(obs.cpu().numpy(), o_ref, rtol=2e-5, atol=2e-5) and np.allclose(reward.cpu().numpy(), r_ref, rtol=2e-5, atol=2e-5)
+    assert np.array_equal(term.cpu().numpy(), te_ref) and np.array_equal(trunc.cpu().numpy(), tr_ref)
+    acts = torch.as_tensor(rng.uniform(-1, 1, (B, K, 2)).astype(np.float32), device=env.device)
+    env.traj_layout = "lane_major"
+    o1, _, l1 = env.vmap_sim_ahead(state, acts, env.tau, env.tau)
+    env.traj_layout = "env_major"
+    o2, _, l2 = env.vmap_sim_ahead(state, acts, env.tau, env.tau)
+    assert torch.equal(o1, o2) and torch.equal(l1.physical_state.i_d, l2.physical_state.i_d)
