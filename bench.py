@@ -46,9 +46,22 @@ WORKLOADS = {
     "pmsm_rk4_f32": ("PMSM", "rk4", torch.float32, 1e-4, 22, 100),
     "acrobot_tsit5_f32": ("ACROBOT", "tsit5", torch.float32, 1e-3, 22, 100),
     "pmsm_euler_f64": ("PMSM", "euler", torch.float64, 1e-4, 21, 100),
+    "pmsm_sat_euler_f32": ("PMSM_SAT", "euler", torch.float32, 1e-4, 22, 100),  # saturated model, synthetic LUT
+    "pmsm_sat_tsit5_f32": ("PMSM_SAT", "tsit5", torch.float32, 1e-4, 22, 100),
 }
 ORACLE_NAME = {"PMSM": "pmsm", "PENDULUM": "pendulum", "MASS_SPRING_DAMPER": "mass_spring_damper", "CART_POLE": "cartpole",
                "ACROBOT": "acrobot", "FLUID_TANK": "fluid_tank"}
+
+
+def synthetic_pmsm_lut(n_d=26, n_q=51):
+    """A smooth saturating machine on the BRUSA current range (synthetic: the reference's motor data is not shipped)."""
+    i_d, i_q = np.linspace(-250.0, 0.0, n_d)[None], np.linspace(-250.0, 250.0, n_q)[None]
+    ID, IQ = np.meshgrid(i_d[0], i_q[0])
+    sat = 1.0 / (1.0 + (ID / 300.0) ** 2 + (IQ / 280.0) ** 2)
+    cross = 2e-5 * np.tanh(ID / 100.0) * np.tanh(IQ / 100.0)
+    return dict(i_d_vec=i_d, i_q_vec=i_q, L_dd=0.37e-3 * (0.6 + 0.4 * sat), L_qq=1.2e-3 * (0.5 + 0.5 * sat), L_dq=cross,
+                L_qd=cross.copy(), Psi_d=65.6e-3 + 0.37e-3 * 300.0 * np.arctan(ID / 300.0),
+                Psi_q=1.2e-3 * 280.0 * np.arctan(IQ / 280.0))
 
 
 def build_env(args, device, rank):
@@ -59,7 +72,12 @@ def build_env(args, device, rank):
     B = args.batch or (1 << log2b)
     Kc = args.chunk or chunk
     solv = {"euler": ex.Euler(), "rk4": ex.RK4(), "tsit5": ex.Tsit5()}[solver]
-    env = getattr(EnvironmentRegistry, reg).make(batch_size=B, tau=tau, solver=solv, dtype=dtype, device=device)
+    if reg == "PMSM_SAT":
+        env = EnvironmentRegistry.PMSM.make(batch_size=B, tau=tau, solver=solv, dtype=dtype, device=device, saturated=True,
+                                            motor_variant=ex.MotorVariant.BRUSA, pmsm_lut=synthetic_pmsm_lut())
+        reg = "PMSM"
+    else:
+        env = getattr(EnvironmentRegistry, reg).make(batch_size=B, tau=tau, solver=solv, dtype=dtype, device=device)
     env.sim_ahead_semantics = args.semantics
     _, state = env.vmap_reset()
     g = torch.Generator(device=device)
@@ -69,7 +87,7 @@ def build_env(args, device, rank):
     if reg == "PMSM":  # stable region omega_el <= 600 rad/s
         ps.i_d = torch.full((B,), -125.0, dtype=dtype, device=device)
         ps.epsilon = u(-np.pi, np.pi)
-        ps.omega_el = u(0.0, 600.0)
+        ps.omega_el = u(0.0, 600.0) if not getattr(env.env_properties, "saturated", False) else u(0.0, 150.0)
     elif reg == "PENDULUM":
         ps.theta, ps.omega = u(-np.pi, np.pi), u(-1.0, 1.0)
     elif reg == "CART_POLE":

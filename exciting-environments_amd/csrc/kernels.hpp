@@ -24,6 +24,7 @@ template <typename T, class M> struct KProps {
   const T* lut_gq;
   const T* lut_tab;
   int32_t lut_nd, lut_nq;
+  int32_t lut_lds;  // 1: the launch reserved dynamic LDS for grids + tables (they are staged there once per workgroup)
 };
 
 template <typename T, class M> struct StepArgs {
@@ -92,6 +93,26 @@ __device__ __forceinline__ void load_ctx(Ctx<T, M>& c, const KProps<T, M>& kp, i
   c.lut_tab = kp.lut_tab;
   c.lut_nd = kp.lut_nd;
   c.lut_nq = kp.lut_nq;
+  c.lut_lds = 0;
+}
+
+// PMSM saturated model: copy the grids and the node-interleaved tables into LDS once per workgroup (47 KB in fp32 —
+// larger than the 32 KB vector L1, so per-lane gathers would otherwise be served by L2). Every thread of the
+// workgroup must call this before any early exit.
+template <class M, typename T>
+__device__ __forceinline__ void stage_lut(Ctx<T, M>& c, const KProps<T, M>& kp) {
+  if constexpr (M::HAS_LUT) {
+    extern __shared__ __align__(16) unsigned char excenv_smem[];
+    if (kp.lut_lds) {
+      T* sm = reinterpret_cast<T*>(excenv_smem);
+      const int ntab = kp.lut_nd * kp.lut_nq * 8;
+      for (int j = threadIdx.x; j < ntab; j += blockDim.x) sm[j] = kp.lut_tab[j];
+      for (int j = threadIdx.x; j < kp.lut_nd; j += blockDim.x) sm[ntab + j] = kp.lut_gd[j];
+      for (int j = threadIdx.x; j < kp.lut_nq; j += blockDim.x) sm[ntab + kp.lut_nd + j] = kp.lut_gq[j];
+      __syncthreads();
+      c.lut_lds = 1;
+    }
+  }
 }
 
 // ---- vector access helpers ---------------------------------------------------------------
@@ -177,9 +198,10 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
   const int64_t blk0 = (int64_t)blockIdx.x * (BLOCK * V);
   const unsigned lane_env = threadIdx.x * V;
   const int64_t i = blk0 + lane_env;
-  if (i >= ka.B) return;
   Ctx<T, M> c;
-  load_ctx<BATCHED>(c, ka.kp, i, ka.dt, ka.env_tau, ka.adv_coef);
+  load_ctx<BATCHED>(c, ka.kp, (i < ka.B) ? i : 0, ka.dt, ka.env_tau, ka.adv_coef);
+  stage_lut<M, T>(c, ka.kp);
+  if (i >= ka.B) return;
   T st[V][S], a[V * A], ob[V * O];
 #pragma unroll
   for (int j = 0; j < S; ++j) {
@@ -265,9 +287,10 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   const int64_t blk0 = (int64_t)blockIdx.x * (BLOCK * V);  // first env of this workgroup
   const unsigned lane_env = threadIdx.x * V;
   const int64_t i0 = blk0 + lane_env;
-  if (i0 >= ka.B) return;  // host guarantees B % V == 0
   Ctx<T, M> c;
-  load_ctx<BATCHED>(c, ka.kp, i0, ka.dt, ka.env_tau, ka.adv_coef);
+  load_ctx<BATCHED>(c, ka.kp, (i0 < ka.B) ? i0 : 0, ka.dt, ka.env_tau, ka.adv_coef);
+  stage_lut<M, T>(c, ka.kp);
+  if (i0 >= ka.B) return;  // host guarantees B % V == 0
 
   T st[V][S];
 #pragma unroll

@@ -70,6 +70,7 @@ static bool fill_props(KProps<T, M>& kp, const excenv_props_t* p) {
   for (int j = 0; j < M::A; ++j) put(p->action_max[j]);
   kp.lut_gd = kp.lut_gq = kp.lut_tab = nullptr;
   kp.lut_nd = kp.lut_nq = 0;
+  kp.lut_lds = 0;
   if (p->pmsm_lut) {
     kp.lut_gd = (const T*)p->pmsm_lut->grid_d;
     kp.lut_gq = (const T*)p->pmsm_lut->grid_q;
@@ -78,6 +79,18 @@ static bool fill_props(KProps<T, M>& kp, const excenv_props_t* p) {
     kp.lut_nq = p->pmsm_lut->n_q;
   }
   return batched;
+}
+
+// Dynamic LDS for the saturated model's tables: staged when they fit the default 64 KiB dynamic-LDS limit.
+template <typename T, class M> static size_t lut_lds_bytes(KProps<T, M>& kp, size_t other) {
+  if constexpr (!M::HAS_LUT) return other;
+  const size_t need = ((size_t)kp.lut_nd * kp.lut_nq * 8 + kp.lut_nd + kp.lut_nq) * sizeof(T);
+  if (kp.lut_tab && need + other <= 64 * 1024) {
+    kp.lut_lds = 1;
+    return need + other;
+  }
+  kp.lut_lds = 0;
+  return other;
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -152,7 +165,8 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
   }
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
-#define EXCENV_STEP_LAUNCH(SOLV, BAT, VV) hipLaunchKernelGGL((step_kernel<M, T, SOLV, BAT, VV>), grid, block, 0, sc.stream, ka)
+  const size_t step_lds = lut_lds_bytes<T, M>(ka.kp, 0);
+#define EXCENV_STEP_LAUNCH(SOLV, BAT, VV) hipLaunchKernelGGL((step_kernel<M, T, SOLV, BAT, VV>), grid, block, step_lds, sc.stream, ka)
 #define EXCENV_STEP_CASE(SOLV)                                             \
   case SOLV:                                                               \
     if (batched) EXCENV_STEP_LAUNCH(SOLV, true, 1);                        \
@@ -171,8 +185,11 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
   return check_launch("excenv_step");
 }
 
-template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(const SimCall& sc, const SimArgs<T, M>& ka,
+template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(const SimCall& sc_in, const SimArgs<T, M>& ka_in,
                                                                                  bool batched, int V) {
+  SimArgs<T, M> ka = ka_in;
+  SimCall sc = sc_in;
+  sc.lds_pad = (int)lut_lds_bytes<T, M>(ka.kp, (size_t)sc_in.lds_pad);
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
   if (batched) {

@@ -19,12 +19,14 @@ template <typename T, class M> struct Ctx {
   const T* lut_gq;
   const T* lut_tab;
   int lut_nd, lut_nq;
+  int lut_lds;  // tables + grids staged in dynamic LDS (layout: tables, grid_d, grid_q)
 };
 
 // ---- Pendulum: pendulum_env.py:144-150,188 ; P = (g,l,m) --------------------------------
 template <typename T> struct Pendulum {
   static constexpr int ID = EXCENV_PENDULUM, S = 2, A = 1, O = 2, P = 3, NY = 2;
   static constexpr bool IS_PMSM = false;
+  static constexpr bool HAS_LUT = false;
   using C = Ctx<T, Pendulum>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; y[1] = st[1]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; st[1] = y[1]; }
@@ -44,6 +46,7 @@ template <typename T> struct Pendulum {
 template <typename T> struct MassSpringDamper {
   static constexpr int ID = EXCENV_MASS_SPRING_DAMPER, S = 2, A = 1, O = 2, P = 3, NY = 2;
   static constexpr bool IS_PMSM = false;
+  static constexpr bool HAS_LUT = false;
   using C = Ctx<T, MassSpringDamper>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; y[1] = st[1]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; st[1] = y[1]; }
@@ -63,6 +66,7 @@ template <typename T> struct MassSpringDamper {
 template <typename T> struct CartPole {
   static constexpr int ID = EXCENV_CART_POLE, S = 4, A = 1, O = 4, P = 6, NY = 4;
   static constexpr bool IS_PMSM = false;
+  static constexpr bool HAS_LUT = false;
   using C = Ctx<T, CartPole>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) {
 #pragma unroll
@@ -99,6 +103,7 @@ template <typename T> struct CartPole {
 template <typename T> struct Acrobot {
   static constexpr int ID = EXCENV_ACROBOT, S = 4, A = 1, O = 4, P = 9, NY = 4;
   static constexpr bool IS_PMSM = false;
+  static constexpr bool HAS_LUT = false;
   using C = Ctx<T, Acrobot>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) {
 #pragma unroll
@@ -143,6 +148,7 @@ template <typename T> struct Acrobot {
 template <typename T> struct FluidTank {
   static constexpr int ID = EXCENV_FLUID_TANK, S = 1, A = 1, O = 1, P = 4, NY = 1;
   static constexpr bool IS_PMSM = false;
+  static constexpr bool HAS_LUT = false;
   using C = Ctx<T, FluidTank>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; }
@@ -162,6 +168,7 @@ template <typename T> struct FluidTank {
 template <typename T> struct Pmsm {
   static constexpr int ID = EXCENV_PMSM, S = 7, A = 2, O = 8, P = 7, NY = 3;
   static constexpr bool IS_PMSM = true;
+  static constexpr bool HAS_LUT = false;
   using C = Ctx<T, Pmsm>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[3]; y[1] = st[4]; y[2] = st[2]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[3] = y[0]; st[4] = y[1]; st[2] = y[2]; }
@@ -254,35 +261,72 @@ template <typename T> struct Pmsm {
 template <typename T> struct PmsmSat {
   static constexpr int ID = EXCENV_PMSM, S = 7, A = 2, O = 8, P = 7, NY = 3;
   static constexpr bool IS_PMSM = true;
+  static constexpr bool HAS_LUT = true;
   using C = Ctx<T, PmsmSat>;
   using L = Pmsm<T>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[3]; y[1] = st[4]; y[2] = st[2]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[3] = y[0]; st[4] = y[1]; st[2] = y[2]; }
 
   // jax.scipy.interpolate.RegularGridInterpolator._find_indices: i = clip(searchsorted(g, x) - 1, 0, n - 2),
-  // t = (x - g[i]) / (g[i+1] - g[i])  (not clipped: linear extrapolation; the padded edge makes it constant)
-  __device__ static __forceinline__ void find(const T* g, int n, T x, int& i, T& t) {
-    int lo = 0, hi = n;
-    while (lo < hi) {  // first index with g[idx] >= x
-      const int mid = (lo + hi) >> 1;
-      if (g[mid] < x) lo = mid + 1; else hi = mid;
+  // t = (x - g[i]) / (g[i+1] - g[i])  (not clipped: linear extrapolation; the padded edge makes it constant).
+  // GP is a pointer to the grid in global memory or (address_space(3)) in LDS.
+  template <class GP> __device__ static __forceinline__ void find(GP g, int n, T x, int& i, T& t) {
+    // The reference's grids are np.linspace: guess the cell arithmetically, then make it exact against the stored
+    // grid values (same result as searchsorted(g, x, side="left") - 1 clipped to [0, n-2]); a non-uniform grid that
+    // defeats the guess falls back to a binary search.
+    const T g0 = g[0], gl = g[n - 1];
+    T gf = (x - g0) * (T(n - 1) / (gl - g0));
+    gf = (gf > T(0)) ? gf : T(0);  // also maps NaN to 0
+    gf = (gf < T(n - 2)) ? gf : T(n - 2);
+    int i0 = (int)gf;
+    T lo = g[i0], hi = g[i0 + 1];
+    if (!(lo < x) && i0 > 0) {
+      --i0;
+      hi = lo;
+      lo = g[i0];
+    } else if (hi < x && i0 < n - 2) {
+      ++i0;
+      lo = hi;
+      hi = g[i0 + 1];
     }
-    i = lo - 1;
-    i = (i < 0) ? 0 : i;
-    i = (i > n - 2) ? n - 2 : i;
-    t = (x - g[i]) / (g[i + 1] - g[i]);
+    const bool ok = (i0 == 0 || lo < x) && (i0 == n - 2 || !(hi < x));
+    if (__builtin_expect(!ok && x == x, 0)) {
+      int l = 0, h = n;
+      while (l < h) {  // first index with g[idx] >= x
+        const int mid = (l + h) >> 1;
+        if (g[mid] < x) l = mid + 1; else h = mid;
+      }
+      i0 = l - 1;
+      i0 = (i0 < 0) ? 0 : i0;
+      i0 = (i0 > n - 2) ? n - 2 : i0;
+      lo = g[i0];
+      hi = g[i0 + 1];
+    }
+    i = i0;
+    t = (x - lo) / (hi - lo);
   }
   // six bilinear look-ups sharing one cell: _evaluate_linear's corner order (i,j), (i,j+1), (i+1,j), (i+1,j+1)
-  __device__ static __forceinline__ void lookup(T i_d, T i_q, const C& c, T (&q)[6]) {
+  template <class GP> __device__ static __forceinline__ void lookup_at(GP gd, GP gq, GP tab, int nd, int nq, T i_d, T i_q, T (&q)[6]) {
     int ix, iy;
     T tx, ty;
-    find(c.lut_gd, c.lut_nd, i_d, ix, tx);
-    find(c.lut_gq, c.lut_nq, i_q, iy, ty);
+    find(gd, nd, i_d, ix, tx);
+    find(gq, nq, i_q, iy, ty);
     const T w00 = (T(1) - tx) * (T(1) - ty), w01 = (T(1) - tx) * ty, w10 = tx * (T(1) - ty), w11 = tx * ty;
-    const T* n00 = c.lut_tab + ((int64_t)ix * c.lut_nq + iy) * 8;
-    const T* n10 = n00 + (int64_t)c.lut_nq * 8;
+    GP n00 = tab + (ix * nq + iy) * 8;
+    GP n10 = n00 + nq * 8;
 #pragma unroll
     for (int k = 0; k < 6; ++k) q[k] = T(0) + n00[k] * w00 + n00[8 + k] * w01 + n10[k] * w10 + n10[8 + k] * w11;
+  }
+  __device__ static __forceinline__ void lookup(T i_d, T i_q, const C& c, T (&q)[6]) {
+    if (c.lut_lds) {  // tables staged in LDS by stage_lut(): statically LDS-typed pointers -> ds_read gathers
+      typedef const __attribute__((address_space(3))) T* LP;
+      extern __shared__ __align__(16) unsigned char excenv_smem[];
+      LP sm = (LP)excenv_smem;
+      const int ntab = c.lut_nd * c.lut_nq * 8;
+      lookup_at<LP>(sm + ntab, sm + ntab + c.lut_nd, sm, c.lut_nd, c.lut_nq, i_d, i_q, q);
+    } else {
+      lookup_at<const T*>(c.lut_gd, c.lut_gq, c.lut_tab, c.lut_nd, c.lut_nq, i_d, i_q, q);
+    }
   }
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&st)[S], T (&dy)[NY]) {
     const T r_s = c.P[1], omega_el = st[6];
