@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""env-steps/s of vmap_sim_ahead (chunk 100, full outputs) and vmap_step vs batch size, PMSM Euler fp32 (run on the GPU box)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "exciting-environments_amd")]
+import torch
+from exciting_environments_amd import EnvironmentRegistry
+
+print("| batch | sim_ahead env-steps/s | GB/s (68 B) | ms/launch | vmap_step env-steps/s | us/step eager |")
+print("|---|---|---|---|---|---|")
+for lb in (10, 12, 14, 16, 18, 20, 22, 24):
+    B, K = 1 << lb, 100
+    env = EnvironmentRegistry.PMSM.make(batch_size=B, device="cuda:0")
+    _, st = env.vmap_reset()
+    st.physical_state.omega_el = torch.rand(B, device="cuda:0") * 600
+    acts = env.new_actions_buffer(K)
+    acts.uniform_(-1, 1)
+    s = st
+    for _ in range(3):
+        o, _, s = env.vmap_sim_ahead(s, acts, env.tau, env.tau)
+    torch.cuda.synchronize()
+    n = max(5, min(200, (1 << 24) // B))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        o, _, s = env.vmap_sim_ahead(s, acts, env.tau, env.tau)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    a0 = acts[:, 0, :].contiguous()
+    del o
+    s2 = st
+    for _ in range(20):
+        ob, s2 = env.vmap_step(s2, a0)
+    torch.cuda.synchronize()
+    m = max(50, min(2000, (1 << 26) // B))
+    t0 = time.perf_counter()
+    for _ in range(m):
+        ob, s2 = env.vmap_step(s2, a0)
+    torch.cuda.synchronize()
+    ds = (time.perf_counter() - t0) / m
+    print(f"| 2^{lb} | {B * K / dt:.3e} | {68 * B * K / dt / 1e9:.0f} | {dt * 1e3:.3f} | {B / ds:.3e} | {ds * 1e6:.1f} |")
+    del env, st, s, s2, acts
+    torch.cuda.empty_cache()
