@@ -340,7 +340,8 @@ def test_tiled_layout_is_lane_major_per_tile():
         assert torch.equal(getattr(last.physical_state, n), getattr(ref_last.physical_state, n))
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (64, 64), (65, 63), (1000, 3), (3, 1000), (4097, 257)])
+@pytest.mark.parametrize("shape", [(1, 1), (64, 64), (65, 63), (1000, 3), (3, 1000), (4097, 257), (808, 4096), (101, 4096),
+                                   (4096, 200), (600, 1028), (1028, 600), (12, 8)])
 def test_transpose_kernel(shape):
     from exciting_environments_amd import _native
 
