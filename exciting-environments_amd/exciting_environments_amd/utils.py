@@ -1,38 +1,49 @@
-"""Normalisation helper and fixture I/O — mirrors reference exciting_environments/utils.py."""
-from dataclasses import asdict, dataclass
+"""Min-max normalisation record and the JSON format of the golden fixtures' ``sim_properties.json``
+(behaviour of reference exciting_environments/utils.py:8-52)."""
+import dataclasses
 import json
 
 
-@dataclass
+@dataclasses.dataclass
 class MinMaxNormalization:
-    """utils.py:8-17. `min`/`max` may be Python scalars or [batch_size] arrays (torch / numpy)."""
+    """Maps [min, max] to [-1, 1] and back. ``min`` / ``max`` are Python scalars or [batch_size] arrays (torch / numpy).
+    The operation order is part of the contract (the kernels reproduce it exactly): utils.py:13-17."""
 
     min: float
     max: float
 
     def normalize(self, denormalized_value):
-        return 2 * (denormalized_value - self.min) / (self.max - self.min) - 1
+        span = self.max - self.min
+        return 2 * (denormalized_value - self.min) / span - 1
 
     def denormalize(self, normalized_value):
-        return (normalized_value + 1) / 2 * (self.max - self.min) + self.min
+        span = self.max - self.min
+        return (normalized_value + 1) / 2 * span + self.min
+
+
+def _bounds_to_plain(norms: dict) -> dict:
+    return {name: {"min": n.min, "max": n.max} for name, n in norms.items()}
+
+
+def _bounds_from_plain(plain: dict) -> dict:
+    return {name: MinMaxNormalization(min=b["min"], max=b["max"]) for name, b in plain.items()}
 
 
 def dump_sim_properties_to_json(params, action_normalizations, physical_normalizations, tau, filename):
-    """utils.py:21-35 (format of the golden fixtures' sim_properties.json)."""
-    data = {
+    """Write {params, action_normalizations, physical_normalizations, tau} in the fixture format."""
+    payload = {
         "params": params,
-        "action_normalizations": {k: asdict(v) for k, v in action_normalizations.items()},
-        "physical_normalizations": {k: asdict(v) for k, v in physical_normalizations.items()},
+        "action_normalizations": _bounds_to_plain(action_normalizations),
+        "physical_normalizations": _bounds_to_plain(physical_normalizations),
         "tau": tau,
     }
-    with open(filename, "w") as f:
-        json.dump(data, f, indent=4)
+    with open(filename, "w") as fh:
+        json.dump(payload, fh, indent=4)
 
 
 def load_sim_properties_from_json(filename):
-    """utils.py:37-52."""
-    with open(filename, "r") as f:
-        data = json.load(f)
-    action_normalizations = {k: MinMaxNormalization(**v) for k, v in data["action_normalizations"].items()}
-    physical_normalizations = {k: MinMaxNormalization(**v) for k, v in data["physical_normalizations"].items()}
-    return data["params"], action_normalizations, physical_normalizations, data["tau"]
+    """Inverse of dump_sim_properties_to_json: (params, action_normalizations, physical_normalizations, tau)."""
+    with open(filename) as fh:
+        payload = json.load(fh)
+    return (payload["params"], _bounds_from_plain(payload["action_normalizations"]),
+            _bounds_from_plain(payload["physical_normalizations"]), payload["tau"])
