@@ -15,10 +15,10 @@ from .registration import EnvironmentRegistry
 from .gym_wrapper import GymWrapper
 from .solvers import Euler, RK4, Tsit5
 from .utils import MinMaxNormalization, dump_sim_properties_to_json, load_sim_properties_from_json
-from . import tree, utils
+from . import random, tree, utils
 
 __all__ = [
     "CoreEnvironment", "Acrobot", "CartPole", "FluidTank", "MassSpringDamper", "Pendulum", "PMSM", "MotorVariant", "prepare_pmsm_lut",
     "EnvironmentRegistry", "GymWrapper", "Euler", "RK4", "Tsit5", "MinMaxNormalization", "dump_sim_properties_to_json",
-    "load_sim_properties_from_json", "tree", "utils",
+    "load_sim_properties_from_json", "random", "tree", "utils",
 ]

@@ -366,13 +366,30 @@ class PMSM(CoreEnvironment):
             phys = dict(u_d_buffer=full(0.0), u_q_buffer=full(0.0), epsilon=full(0.0), i_d=full((i_lo + i_hi) / 2),
                         i_q=full(0.0), torque=full(0.0), omega_el=full((o_lo + o_hi) / 2))
         else:
-            gen = rng
-            if not isinstance(rng, torch.Generator):
-                gen = torch.Generator(device=self.device)
-                gen.manual_seed(int(rng))
-            u = lambda: torch.rand(shape, generator=gen, dtype=self.dtype, device=self.device)
-            state_norm = [u() * 2 - 1, u() * 2 - 1]
-            r, phi = torch.sqrt(u()), u() * (2 * math.pi)  # uniform in the unit disc (jax.random.ball(key, 2))
+            from . import random as _random
+
+            key_leaf = None
+            if _random.is_key(rng):
+                # pmsm_env.py:403-406: rng, subkey = split(rng); uniform(subkey, (2,), -1, 1); rng, subkey = split(rng);
+                # ball(subkey, 2). eps / omega follow the key stream; jax.random.ball (gamma rejection sampling) is not
+                # restated: the disc point is drawn from two further uniform words of the second subkey.
+                k = rng.to(self.device)
+                assert tuple(k.shape[:-1]) == tuple(shape), f"rng keys must have shape {tuple(shape) + (2,)}"
+                s1 = _random.split(k)
+                sn = _random.uniform(s1[..., 1, :], 2, self.dtype, -1.0, 1.0)
+                s2 = _random.split(s1[..., 0, :])
+                w = _random.uniform(s2[..., 1, :], 2, self.dtype, 0.0, 1.0)
+                state_norm = [sn[..., 0], sn[..., 1]]
+                r, phi = torch.sqrt(w[..., 0]), w[..., 1] * (2 * math.pi)
+                key_leaf = s2[..., 0, :]
+            else:
+                gen = rng
+                if not isinstance(rng, torch.Generator):
+                    gen = torch.Generator(device=self.device)
+                    gen.manual_seed(int(rng))
+                u = lambda: torch.rand(shape, generator=gen, dtype=self.dtype, device=self.device)
+                state_norm = [u() * 2 - 1, u() * 2 - 1]
+                r, phi = torch.sqrt(u()), u() * (2 * math.pi)  # uniform in the unit disc (jax.random.ball(key, 2))
             (d_lo, d_hi), (q_lo, q_hi) = lo_hi("i_d"), lo_hi("i_q")
             i_max = torch.as_tensor(max(abs(float(torch.as_tensor(v).max())) for v in (d_lo, d_hi, q_lo, q_hi)))
             i_d, i_q = r * torch.cos(phi) * i_max, r * torch.sin(phi) * i_max
@@ -391,7 +408,10 @@ class PMSM(CoreEnvironment):
                         epsilon=(state_norm[0] + 1) / 2 * (e_hi - e_lo) + e_lo, i_d=i_d, i_q=i_q, torque=torque,
                         omega_el=(state_norm[1] + 1) / 2 * (o_hi - o_lo) + o_lo)
         ref = {n: self._nan(shape) for n in self.STATE_FIELDS}
-        return self.State(physical_state=self.PhysicalState(**phys), PRNGKey=self._nan(shape),
+        prng = self._nan(shape)
+        if rng is not None and key_leaf is not None:
+            prng = key_leaf
+        return self.State(physical_state=self.PhysicalState(**phys), PRNGKey=prng,
                           additions=self._additions(shape, False), reference=self.PhysicalState(**ref))
 
     def generate_observation(self, system_state, env_properties):
