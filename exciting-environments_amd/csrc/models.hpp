@@ -365,10 +365,6 @@ template <typename T> struct PmsmSat {
 // ---- reward / truncated / terminated (reference generate_reward / generate_truncated / generate_terminated) -----
 // What GymWrapper.gym_step evaluates after every vmap_step (gym_wrapper.py:117-126). `ref[j]` is the physical
 // reference value of state field idx[j] (control_state order).
-template <class M> struct RttInfo {  // width of the truncated flag row
-  __host__ __device__ static constexpr bool one_flag() { return M::ID == EXCENV_FLUID_TANK || M::ID == EXCENV_PMSM; }
-};
-
 template <class M> __host__ __device__ constexpr bool is_angle_field(int f) {
   return (M::ID == EXCENV_PENDULUM && f == 0) || (M::ID == EXCENV_CART_POLE && f == 2) ||
          (M::ID == EXCENV_ACROBOT && (f == 0 || f == 1));
