@@ -108,6 +108,7 @@ def build_env(args, device, rank):
         del flat
     env.traj_layout = args.traj_layout
     env.env_major_workspace = not getattr(args, "no_workspace", False)
+    env.env_major_fused = not getattr(args, "no_fused", False)
     env.store_state_trajectory = not getattr(args, "obs_only", False)
     return env, state, actions, B, Kc, reg, solver, dtype
 
@@ -188,7 +189,8 @@ def main():
     ap.add_argument("--path", default="sim_ahead", choices=["sim_ahead", "step"],
                     help="sim_ahead: one persistent launch per bench step (headline); step: one vmap_step launch per bench step")
     ap.add_argument("--obs-only", action="store_true", help="skip the state trajectories (not the reference's full outputs)")
-    ap.add_argument("--no-workspace", action="store_true", help="env-major buffers: use the generic-stride kernel path")
+    ap.add_argument("--no-workspace", action="store_true", help="env-major buffers: no transposition workspace")
+    ap.add_argument("--no-fused", action="store_true", help="env-major buffers: do not use the fused LDS time-tile kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -54,6 +54,7 @@ static const EnvVTable* table_for(int env, const excenv_props_t* props, int* rc)
 
 static int g_vec_pref = 0;
 static int g_lds_pad = 0;
+static int g_em_mode = 0;
 
 static int check_common(const char* fn, int env, int solver, int dtype, int64_t B) {
   if (env < 0 || env >= EXCENV_NUM_ENVS) { set_error("%s: bad env id %d", fn, env); return EXCENV_EINVAL; }
@@ -113,6 +114,7 @@ int64_t excenv_sim_ahead_bytes(int env, int dtype, int with_state_traj) {
 int excenv_set_tuning(int key, int value) {
   if (key == 0) { int old = g_vec_pref; g_vec_pref = value; return old; }
   if (key == 1) { int old = g_lds_pad; g_lds_pad = value < 0 ? 0 : value; return old; }
+  if (key == 2) { int old = g_em_mode; g_em_mode = value; return old; }
   return EXCENV_EINVAL;
 }
 
@@ -197,11 +199,15 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
   const int nc = control ? control->n_control : 0;
   const int64_t need = excenv_sim_ahead_workspace_bytes(env, dtype, B, K, substeps, nc, action_layout, traj_layout,
                                                         state_traj != nullptr);
-  const bool via_ws = workspace && need > 0 && workspace_bytes >= need && B > 0 &&
+  const int64_t wbytes = dtype == EXCENV_F64 ? 8 : 4;
+  const bool fused_em = g_em_mode != 1 && action_layout == EXCENV_LAYOUT_ENV_MAJOR && traj_layout == EXCENV_LAYOUT_ENV_MAJOR &&
+                        substeps == 1 &&
+                        (int64_t)em_lds_elems<float>(t->A, t->O + nc, t->S, state_traj != nullptr) * wbytes <= 64 * 1024;
+  const bool via_ws = !fused_em && workspace && need > 0 && workspace_bytes >= need && B > 0 &&
                       (action_layout == EXCENV_LAYOUT_ENV_MAJOR || traj_layout == EXCENV_LAYOUT_ENV_MAJOR);
   if (!via_ws) {
     SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, actions, action_layout,
-               obs_traj, state_traj, traj_layout, last_state, semantics, g_vec_pref, g_lds_pad, (hipStream_t)stream};
+               obs_traj, state_traj, traj_layout, last_state, semantics, g_vec_pref, g_lds_pad, g_em_mode, (hipStream_t)stream};
     return t->sim(sc);
   }
   // env-major buffers + workspace: transpose in, run the coalesced lane-major kernel, transpose out
@@ -229,7 +235,7 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
     k_tlayout = EXCENV_LAYOUT_LANE_MAJOR;
   }
   SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, k_actions, k_alayout,
-             k_obs, k_straj_p, k_tlayout, last_state, semantics, g_vec_pref, g_lds_pad, st};
+             k_obs, k_straj_p, k_tlayout, last_state, semantics, g_vec_pref, g_lds_pad, g_em_mode, st};
   if (int rc = t->sim(sc)) return rc;
   if (traj_layout == EXCENV_LAYOUT_ENV_MAJOR) {
     if (int rc = launch_transpose(dtype, (N + 1) * OW, B, k_obs, obs_traj, st)) { set_error("excenv_sim_ahead: obs transpose failed"); return rc; }

@@ -4,7 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
-#include "kernels.hpp"
+#include "kernels_em.hpp"
 
 namespace excenv {
 
@@ -44,6 +44,7 @@ struct SimCall {
   int semantics;
   int vec_pref;  // 0 auto, else forced envs-per-lane (1, 2, 4)
   int lds_pad;   // dynamic LDS bytes per workgroup (occupancy shaping experiments; 0 = none)
+  int em_mode;   // env-major buffers: 0 = fused LDS time-tile kernel when eligible, 1 = never (generic strides / workspace)
   hipStream_t stream;
 };
 
@@ -267,6 +268,32 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     }
   }
 
+  if (sc.action_layout == EXCENV_LAYOUT_ENV_MAJOR && sc.traj_layout == EXCENV_LAYOUT_ENV_MAJOR && sc.substeps == 1 &&
+      sc.em_mode != 1) {
+    // fused env-major kernel: one wave per 64 envs, TK steps staged in LDS, per-env contiguous runs written out
+    const size_t lds = em_lds_elems<T>(M::A, (int)OW, M::S, sc.state_traj != nullptr) * sizeof(T);
+    if (lds <= 64 * 1024) {
+      const dim3 grid((unsigned)((sc.B + EM_LANES - 1) / EM_LANES)), block(EM_LANES);
+#define EXCENV_EM_CASE(SOLV)                                                                                             \
+  case SOLV:                                                                                                             \
+    if (sc.semantics == EXCENV_SEM_AHEAD) {                                                                              \
+      if (batched) hipLaunchKernelGGL((sim_ahead_em_kernel<M, T, SOLV, true, true>), grid, block, lds, sc.stream, ka);   \
+      else hipLaunchKernelGGL((sim_ahead_em_kernel<M, T, SOLV, true, false>), grid, block, lds, sc.stream, ka);          \
+    } else {                                                                                                             \
+      if (batched) hipLaunchKernelGGL((sim_ahead_em_kernel<M, T, SOLV, false, true>), grid, block, lds, sc.stream, ka);  \
+      else hipLaunchKernelGGL((sim_ahead_em_kernel<M, T, SOLV, false, false>), grid, block, lds, sc.stream, ka);         \
+    }                                                                                                                    \
+    break;
+      switch (sc.solver) {
+        EXCENV_EM_CASE(EXCENV_EULER)
+        EXCENV_EM_CASE(EXCENV_RK4)
+        EXCENV_EM_CASE(EXCENV_TSIT5)
+        default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
+      }
+#undef EXCENV_EM_CASE
+      return check_launch("excenv_sim_ahead (env-major fused)");
+    }
+  }
   vec_ok &= (sc.action_layout != EXCENV_LAYOUT_ENV_MAJOR) && (sc.traj_layout != EXCENV_LAYOUT_ENV_MAJOR);
   vec_ok &= aligned16(ka.actions) && aligned16(ka.obs);
   constexpr int VMAX = 16 / (int)sizeof(T);

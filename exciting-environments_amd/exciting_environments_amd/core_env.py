@@ -96,7 +96,9 @@ class CoreEnvironment(ABC):
         self.traj_layout = "lane_major"
         # "ahead": structure of the reference's _ode_solver_simulate_ahead; "step": K exact `step`s.
         self.sim_ahead_semantics = "ahead"
-        # env-major buffers: True = transpose through a scratch workspace (fast), False = generic-stride kernel path
+        # env-major (row-major) buffers, three bit-identical paths: fused LDS time-tile kernel (default when both actions and
+        # trajectories are env-major), else transposition through a scratch workspace, else the generic-stride kernel
+        self.env_major_fused = True
         self.env_major_workspace = True
         # False: vmap_sim_ahead skips the physical-state trajectories (`states` is None; 40 instead of 68 bytes per
         # PMSM env-step). The reference always returns them, so the default is True.
@@ -548,6 +550,8 @@ class CoreEnvironment(ABC):
                                                        a_layout, t_layout, want_states)
             if nbytes > 0:
                 workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        if _native.LAYOUT_ENV_MAJOR in (a_layout, t_layout):
+            _native.set_tuning(2, 0 if self.env_major_fused else 1)
         _native.sim_ahead(self.ENV_ID, self._solver.id, self.dtype, B, K, sub, props, control, float(obs_stepsize),
                           float(self.tau), st_in, actions, a_layout, obs_buf, st_buf, t_layout, last, sem, workspace)
         return observations, st_views, last, N

@@ -23,7 +23,7 @@ def _draw(rng):
         K=int(rng.choice([0, 1, 2, 7, 16, 33])),
         substeps=1 if env_name == "pmsm" else int(rng.choice([1, 1, 2, 3])),
         semantics=["step", "ahead"][rng.integers(2)],
-        layout=["lane_major", "env_major", "env_major_nows"][rng.integers(3)],
+        layout=["lane_major", "env_major", "env_major_ws", "env_major_strided"][rng.integers(4)],
         lane_actions=bool(rng.integers(2)),
     )
     spec = spec_of(env_name)
@@ -55,7 +55,8 @@ def test_random_configuration_matches_oracle(seed):
     env, props, keep, _ = make_env(env_name, B, dtype, cfg["solver"], spec=spec, control_state=cfg["control"] or None)
     env.sim_ahead_semantics = cfg["semantics"]
     env.traj_layout = "lane_major" if cfg["layout"] == "lane_major" else "env_major"
-    env.env_major_workspace = cfg["layout"] != "env_major_nows"
+    env.env_major_fused = cfg["layout"] == "env_major"
+    env.env_major_workspace = cfg["layout"] != "env_major_strided"
     st = random_state(env_name, B, npdt, spec, seed=2000 + seed)
     refs = {}
     for n in cfg["control"]:

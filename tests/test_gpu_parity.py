@@ -155,15 +155,18 @@ def test_envs_per_lane_variants_are_bit_identical(env_name, vec):
     a_lane.copy_(torch.as_tensor(acts, device=env.device))
     a_env = torch.as_tensor(acts, device=env.device)
     env.traj_layout = "env_major"
-    env.env_major_workspace = False  # generic-stride kernel path
+    env.env_major_fused, env.env_major_workspace = False, False  # generic-stride kernel path
     ref_obs, ref_states, ref_last = env.vmap_sim_ahead(to_state(env, st), a_env, env.tau, env.tau)
     assert ref_obs.is_contiguous()
-    env.env_major_workspace = True  # transposing path through a workspace: same bits, contiguous row-major result
-    ws_obs, ws_states, ws_last = env.vmap_sim_ahead(to_state(env, st), a_env, env.tau, env.tau)
-    assert ws_obs.is_contiguous() and torch.equal(ws_obs, ref_obs)
-    for n in env.STATE_FIELDS:
-        assert torch.equal(getattr(ws_states.physical_state, n), getattr(ref_states.physical_state, n))
-        assert torch.equal(getattr(ws_last.physical_state, n), getattr(ref_last.physical_state, n))
+    # transposition through a workspace, then the fused LDS time-tile kernel: same bits, contiguous row-major results
+    for fused, ws in ((False, True), (True, False)):
+        env.env_major_fused, env.env_major_workspace = fused, ws
+        ws_obs, ws_states, ws_last = env.vmap_sim_ahead(to_state(env, st), a_env, env.tau, env.tau)
+        assert ws_obs.is_contiguous() and torch.equal(ws_obs, ref_obs), (fused, ws)
+        for n in env.STATE_FIELDS:
+            assert torch.equal(getattr(ws_states.physical_state, n), getattr(ref_states.physical_state, n))
+            assert torch.equal(getattr(ws_last.physical_state, n), getattr(ref_last.physical_state, n))
+    env.env_major_fused, env.env_major_workspace = True, True
     env.traj_layout = "lane_major"
     old = _native.set_tuning(0, vec)
     try:
