@@ -8,13 +8,33 @@
 
 namespace excenv {
 
-constexpr int EM_TK = 8;      // solver steps staged per tile
+#ifndef EXCENV_EM_TK
+#define EXCENV_EM_TK 8
+#endif
+constexpr int EM_TK = EXCENV_EM_TK;  // solver steps staged per tile
 constexpr int EM_LANES = 64;  // one wave per workgroup
 
 template <typename T> __host__ __device__ constexpr size_t em_lds_elems(int A, int OW, int S, bool with_states) {
   return (size_t)EM_LANES * ((EM_TK + 1) * A + 1) + (size_t)EM_LANES * (EM_TK * OW + 1) +
          (with_states ? (size_t)S * EM_LANES * (EM_TK + 1) : 0);
 }
+
+// Walks idx = lane, lane + 64, ... over a [nenv][per] index space without per-iteration divisions:
+// (e, j) = (idx / per, idx % per) advanced by (64 / per, 64 % per) with carry.
+struct EmWalk {
+  int e, j, qe, qj, per;
+  __device__ __forceinline__ EmWalk(int lane, int per_) : per(per_) {
+    e = lane / per_;
+    j = lane - e * per_;
+    qe = EM_LANES / per_;
+    qj = EM_LANES - qe * per_;
+  }
+  __device__ __forceinline__ void next() {
+    e += qe;
+    j += qj;
+    if (j >= per) { j -= per; ++e; }
+  }
+};
 
 template <class M, typename T, int SOLVER, bool AHEAD, bool BATCHED>
 __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T, M> ka) {
@@ -62,20 +82,43 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
   }
 
   const int64_t N = ka.K;  // substeps == 1 on this path (host)
-  for (int64_t n0 = 0; n0 <= N; n0 += TK) {
-    const int cnt = (int)((N + 1 - n0 < TK) ? (N + 1 - n0) : TK);               // rows n0 .. n0+cnt-1
-    int na = (int)((ka.K - n0 < TK + 1) ? (ka.K - n0) : (TK + 1));               // actions n0 .. n0+na-1 (one ahead)
-    na = na < 0 ? 0 : na;
-    // ---- action tile: every env's na*A words are contiguous in [B][K][A] ----
-    {
-      const int per = na * A;
-      const T* src = ka.actions + (b0 * ka.K + n0) * A;
-      for (int idx = lane; idx < nenv * per; idx += EM_LANES) {
-        const int e = idx / per, j = idx - e * per;
-        tact[e * LDA + j] = src[(int64_t)e * ka.K * A + j];
-      }
+  // Action tiles are prefetched one tile ahead into registers (NA_IT words per lane, all loads in flight together) and
+  // parked in LDS after the compute phase, so their HBM latency hides behind TK solver steps.
+  constexpr int NA_IT = (TK + 1) * A;
+  T areg[NA_IT];
+  auto na_of = [&](int64_t n0) -> int {
+    int64_t na = ka.K - n0;
+    na = na < (TK + 1) ? na : (TK + 1);
+    return (int)(na < 0 ? 0 : na);
+  };
+  auto fetch_actions = [&](int64_t n0) {  // global -> registers, no wait
+    const int per = na_of(n0) * A;
+    if (per == 0) return;
+    const T* src = ka.actions + (b0 * ka.K + n0) * A;
+    EmWalk w(lane, per);
+#pragma unroll
+    for (int it = 0; it < NA_IT; ++it) {
+      if (w.e < nenv) areg[it] = src[(int64_t)w.e * ka.K * A + w.j];
+      w.next();
     }
-    __syncthreads();
+  };
+  auto park_actions = [&](int64_t n0) {  // registers -> LDS
+    const int per = na_of(n0) * A;
+    if (per == 0) return;
+    EmWalk w(lane, per);
+#pragma unroll
+    for (int it = 0; it < NA_IT; ++it) {
+      if (w.e < nenv) tact[w.e * LDA + w.j] = areg[it];
+      w.next();
+    }
+  };
+  fetch_actions(0);
+  park_actions(0);
+  for (int64_t n0 = 0; n0 <= N; n0 += TK) {
+    const int cnt = (int)((N + 1 - n0 < TK) ? (N + 1 - n0) : TK);  // rows n0 .. n0+cnt-1
+    const int na = na_of(n0);                                      // actions n0 .. n0+na-1 (one ahead)
+    __syncthreads();                                               // action tile parked; previous flush has read its rows
+    fetch_actions(n0 + TK);                                        // next tile's loads fly during this tile's steps
     // ---- TK solver steps, rows staged in LDS ----
     T sv[S];
     for (int t = 0; t < cnt; ++t) {
@@ -128,28 +171,22 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
       T* dst = ka.obs + (b0 * (N + 1) + n0) * OW;
       constexpr int VW = 16 / (int)sizeof(T);  // elements per 16-byte piece
       if ((OW % VW) == 0) {  // every env row and tile start is then 16-byte aligned
-        const int perv = per / VW;
-        for (int idx = lane; idx < nenv * perv; idx += EM_LANES) {
-          const int e = idx / perv, j = (idx - e * perv) * VW;
+        for (EmWalk w(lane, per / VW); w.e < nenv; w.next()) {
+          const int j = w.j * VW;
           T v[VW];
 #pragma unroll
-          for (int q = 0; q < VW; ++q) v[q] = tobs[e * LDO + j + q];
-          store_v<T, VW>(dst + (int64_t)e * (N + 1) * OW + j, v);
+          for (int q = 0; q < VW; ++q) v[q] = tobs[w.e * LDO + j + q];
+          store_v<T, VW>(dst + (int64_t)w.e * (N + 1) * OW + j, v);
         }
       } else {
-        for (int idx = lane; idx < nenv * per; idx += EM_LANES) {
-          const int e = idx / per, j = idx - e * per;
-          dst[(int64_t)e * (N + 1) * OW + j] = tobs[e * LDO + j];
-        }
+        for (EmWalk w(lane, per); w.e < nenv; w.next()) dst[(int64_t)w.e * (N + 1) * OW + w.j] = tobs[w.e * LDO + w.j];
       }
       if (with_states) {
+        const EmWalk w0(lane, cnt);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           T* sd = ka.straj[s] + b0 * (N + 1) + n0;
-          for (int idx = lane; idx < nenv * cnt; idx += EM_LANES) {
-            const int e = idx / cnt, t = idx - e * cnt;
-            sd[(int64_t)e * (N + 1) + t] = tst[(s * EM_LANES + e) * LDS_ + t];
-          }
+          for (EmWalk w = w0; w.e < nenv; w.next()) sd[(int64_t)w.e * (N + 1) + w.j] = tst[(s * EM_LANES + w.e) * LDS_ + w.j];
         }
       }
     }
@@ -159,7 +196,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
         for (int j = 0; j < S; ++j) ka.last_state[j][i0] = sv[j];
       }
     }
-    // the barrier after the next action-tile load also orders this flush before the next compute phase
+    park_actions(n0 + TK);  // this tile's steps are done with tact (barrier above), the next barrier publishes it
   }
 }
 
