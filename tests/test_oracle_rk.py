@@ -120,3 +120,57 @@ def test_rk4_ahead_first_step_by_hand():
                                        semantics=sem)
         got = np.array([straj[0][0, 1], straj[1][0, 1]])
         assert np.allclose(got, want, rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("env,solver,tol", [("pendulum", "tsit5", 2e-10), ("pendulum", "rk4", 5e-8), ("acrobot", "tsit5", 5e-9),
+                                            ("cartpole", "tsit5", 5e-9)])
+def test_nonlinear_systems_against_independent_scipy_integration(env, solver, tol):
+    """Constant action, 200 fixed steps: the oracle's RK trajectory vs scipy's DOP853 (rtol 1e-13) on the same vector
+    field written independently here from the reference formulas (pendulum_env.py:144-150, acrobot_env.py:171-197,
+    cart_pole_env.py:159-180)."""
+    from scipy.integrate import solve_ivp
+    from conftest import load_golden
+
+    g = load_golden(env)
+    p = g["params"]
+    a_norm = 0.3
+    (lo, hi), = g["act_norm"].values()
+    u = oracle.denormalize(a_norm, lo, hi)
+    if env == "pendulum":
+        y0 = np.array([0.4, -0.3])
+        f = lambda t, y: [y[1], (u + p["l"] * p["m"] * p["g"] * np.sin(y[0])) / (p["m"] * p["l"] ** 2)]
+    elif env == "acrobot":
+        y0 = np.array([0.5, -0.4, 0.2, 0.1])
+
+        def f(t, y):
+            th1, th2, w1, w2 = y
+            m1, m2, l1, lc1, lc2, I1, I2, gg = p["m_1"], p["m_2"], p["l_1"], p["l_c1"], p["l_c2"], p["I_1"], p["I_2"], p["g"]
+            d11 = m1 * lc1**2 + m2 * (l1**2 + lc2**2 + 2 * l1 * lc2 * np.cos(th2)) + I1 + I2
+            d12 = m2 * (lc2**2 + l1 * lc2 * np.cos(th2)) + I2
+            d22 = m2 * lc2**2 + I2
+            h1 = -m2 * l1 * lc2 * np.sin(th2) * w2**2 - 2 * m2 * l1 * lc2 * np.sin(th2) * w1 * w2
+            h2 = m2 * l1 * lc2 * np.sin(th2) * w1**2
+            phi1 = (m1 * lc1 + m2 * l1) * gg * np.cos(th1 + np.pi / 2) + m2 * lc2 * gg * np.cos(th1 + th2 + np.pi / 2)
+            phi2 = m2 * lc2 * gg * np.cos(th1 + th2 + np.pi / 2)
+            dw1 = 1 / (d12 - d22 / d12 * d11) * (u + d22 / d12 * (h1 + phi1) - h2 - phi2)
+            dw2 = (-d11 * dw1 - h1 - phi1) / d12
+            return [w1, w2, dw1, dw2]
+    else:
+        y0 = np.array([0.1, 0.5, 0.3, -0.2])
+
+        def f(t, y):
+            x, v, th, w = y
+            mp, mc, l, mup, muc, gg = p["m_p"], p["m_c"], p["l"], p["mu_p"], p["mu_c"], p["g"]
+            dw = (gg * np.sin(th) + np.cos(th) * ((-u - mp * l * w**2 * np.sin(th) + muc * np.sign(v)) / (mc + mp))
+                  - (mup * w) / (mp * l)) / (l * (4 / 3 - (mp * np.cos(th) ** 2) / (mc + mp)))
+            dv = (u + mp * l * (w**2 * np.sin(th) - dw * np.cos(th)) - muc * np.sign(v)) / (mc + mp)
+            return [v, dv, w, dw]
+    n, tau = 200, 1e-3
+    ref = solve_ivp(f, (0, n * tau), y0, method="DOP853", rtol=1e-13, atol=1e-15).y[:, -1]
+    pn = {k: (-1e3, 1e3) for k in g["phys_norm"]}  # wide box: no observation saturation matters here
+    props, keep = oracle.make_props(env, p, pn, g["act_norm"], np.float64, 1)
+    st = [np.array([v]) for v in y0]
+    _, straj, last = oracle.sim_ahead(env, solver, st, np.full((1, n, 1), a_norm), props, tau, semantics=oracle.SEM_AHEAD)
+    got = np.array([s[0, -1] for s in straj])
+    # SEM_AHEAD saves wrapped angles; the short horizon keeps them inside (-pi, pi)
+    assert np.abs(got - ref).max() < tol, (got, ref)
