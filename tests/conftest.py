@@ -17,6 +17,13 @@ ENV_NAMES = ["pendulum", "mass_spring_damper", "cartpole", "acrobot", "fluid_tan
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # fresh checkout: the in-tree HIP library / oracle are build artefacts (git-ignored) — build them once with hipcc / gcc
+    lib = os.path.join(PKG_ROOT, "exciting_environments_amd", "lib", "libexcenv_hip.so")
+    if not os.path.exists(lib) and "EXCENV_HIP_LIB" not in os.environ:
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(PKG_ROOT, "csrc"), "-j", str(min(8, os.cpu_count() or 1))], check=True,
+                       capture_output=True)
 
 
 def load_golden(env):
