@@ -48,6 +48,7 @@ WORKLOADS = {
     "pmsm_euler_f64": ("PMSM", "euler", torch.float64, 1e-4, 21, 100),
     "pmsm_sat_euler_f32": ("PMSM_SAT", "euler", torch.float32, 1e-4, 22, 100),  # saturated model, synthetic LUT
     "pmsm_sat_tsit5_f32": ("PMSM_SAT", "tsit5", torch.float32, 1e-4, 22, 100),
+    "pmsm_sat_euler_f64": ("PMSM_SAT", "euler", torch.float64, 1e-4, 21, 100),
 }
 ORACLE_NAME = {"PMSM": "pmsm", "PENDULUM": "pendulum", "MASS_SPRING_DAMPER": "mass_spring_damper", "CART_POLE": "cartpole",
                "ACROBOT": "acrobot", "FLUID_TANK": "fluid_tank"}

@@ -82,11 +82,19 @@ static bool fill_props(KProps<T, M>& kp, const excenv_props_t* p) {
   return batched;
 }
 
-// Dynamic LDS for the saturated model's tables: staged when they fit the default 64 KiB dynamic-LDS limit.
+// Launch with dynamic LDS; above the default 64 KiB limit the kernel's attribute is raised first (gfx950: 160 KiB per CU).
+#define EXCENV_LAUNCH_DYN(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS)                                                         \
+  do {                                                                                                                   \
+    if ((LDS) > 64 * 1024)                                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+    hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS);                                                          \
+  } while (0)
+
+// Dynamic LDS for the saturated model's tables: staged when they fit LDS (<= 150 KiB, leaving room for one workgroup).
 template <typename T, class M> static size_t lut_lds_bytes(KProps<T, M>& kp, size_t other) {
   if constexpr (!M::HAS_LUT) return other;
   const size_t need = ((size_t)kp.lut_nd * kp.lut_nq * 8 + kp.lut_nd + kp.lut_nq) * sizeof(T);
-  if (kp.lut_tab && need + other <= 64 * 1024) {
+  if (kp.lut_tab && need + other <= 150 * 1024) {
     kp.lut_lds = 1;
     return need + other;
   }
@@ -167,7 +175,7 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
   const size_t step_lds = lut_lds_bytes<T, M>(ka.kp, 0);
-#define EXCENV_STEP_LAUNCH(SOLV, BAT, VV) hipLaunchKernelGGL((step_kernel<M, T, SOLV, BAT, VV>), grid, block, step_lds, sc.stream, ka)
+#define EXCENV_STEP_LAUNCH(SOLV, BAT, VV) EXCENV_LAUNCH_DYN((step_kernel<M, T, SOLV, BAT, VV>), grid, block, step_lds, sc.stream, ka)
 #define EXCENV_STEP_CASE(SOLV)                                             \
   case SOLV:                                                               \
     if (batched) EXCENV_STEP_LAUNCH(SOLV, true, 1);                        \
@@ -194,14 +202,14 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
   if (batched) {
-    hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, true, 1>), grid, block, sc.lds_pad, sc.stream, ka);
+    EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, true, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
     return;
   }
   if constexpr (sizeof(T) == 4) {
-    if (V == 4) { hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 4>), grid, block, sc.lds_pad, sc.stream, ka); return; }
+    if (V == 4) { EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 4>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); return; }
   }
-  if (V == 2) { hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 2>), grid, block, sc.lds_pad, sc.stream, ka); return; }
-  hipLaunchKernelGGL((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 1>), grid, block, sc.lds_pad, sc.stream, ka);
+  if (V == 2) { EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 2>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); return; }
+  EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
 }
 
 template <class M, typename T> static int launch_sim(const SimCall& sc) {
