@@ -202,7 +202,7 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
   const int64_t wbytes = dtype == EXCENV_F64 ? 8 : 4;
   const bool fused_em = g_em_mode != 1 && action_layout == EXCENV_LAYOUT_ENV_MAJOR && traj_layout == EXCENV_LAYOUT_ENV_MAJOR &&
                         substeps == 1 &&
-                        (int64_t)em_lds_elems<float>(t->A, t->O + nc, t->S, state_traj != nullptr) * wbytes <= 64 * 1024;
+                        (int64_t)em_lds_elems<float>(t->A, t->O + nc, t->S, state_traj != nullptr) * wbytes <= 150 * 1024;
   const bool via_ws = !fused_em && workspace && need > 0 && workspace_bytes >= need && B > 0 &&
                       (action_layout == EXCENV_LAYOUT_ENV_MAJOR || traj_layout == EXCENV_LAYOUT_ENV_MAJOR);
   if (!via_ws) {

@@ -280,16 +280,16 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
       sc.em_mode != 1) {
     // fused env-major kernel: one wave per 64 envs, TK steps staged in LDS, per-env contiguous runs written out
     const size_t lds = em_lds_elems<T>(M::A, (int)OW, M::S, sc.state_traj != nullptr) * sizeof(T);
-    if (lds <= 64 * 1024) {
+    if (lds <= 150 * 1024) {
       const dim3 grid((unsigned)((sc.B + EM_LANES - 1) / EM_LANES)), block(EM_LANES);
 #define EXCENV_EM_CASE(SOLV)                                                                                             \
   case SOLV:                                                                                                             \
     if (sc.semantics == EXCENV_SEM_AHEAD) {                                                                              \
-      if (batched) hipLaunchKernelGGL((sim_ahead_em_kernel<M, T, SOLV, true, true>), grid, block, lds, sc.stream, ka);   \
-      else hipLaunchKernelGGL((sim_ahead_em_kernel<M, T, SOLV, true, false>), grid, block, lds, sc.stream, ka);          \
+      if (batched) EXCENV_LAUNCH_DYN((sim_ahead_em_kernel<M, T, SOLV, true, true>), grid, block, lds, sc.stream, ka);   \
+      else EXCENV_LAUNCH_DYN((sim_ahead_em_kernel<M, T, SOLV, true, false>), grid, block, lds, sc.stream, ka);          \
     } else {                                                                                                             \
-      if (batched) hipLaunchKernelGGL((sim_ahead_em_kernel<M, T, SOLV, false, true>), grid, block, lds, sc.stream, ka);  \
-      else hipLaunchKernelGGL((sim_ahead_em_kernel<M, T, SOLV, false, false>), grid, block, lds, sc.stream, ka);         \
+      if (batched) EXCENV_LAUNCH_DYN((sim_ahead_em_kernel<M, T, SOLV, false, true>), grid, block, lds, sc.stream, ka);  \
+      else EXCENV_LAUNCH_DYN((sim_ahead_em_kernel<M, T, SOLV, false, false>), grid, block, lds, sc.stream, ka);         \
     }                                                                                                                    \
     break;
       switch (sc.solver) {

@@ -187,7 +187,7 @@ int excenv_transpose(int dtype, int64_t M, int64_t N, const void* in, void* out,
 /* ---- tuning (no reference counterpart) -------------------------------------------------------
  * key 0: environments per lane for lane-major trajectories (0 = auto, 1/2/4 = forced). Process-wide.
  * key 2: env-major (row-major) buffers — 0 (default): fused LDS time-tile kernel when both layouts are env-major,
- *        substeps == 1 and the tile fits 64 KiB of LDS; 1: never (workspace + transposes, or generic strides).
+ *        substeps == 1 and the tile fits 150 KiB of LDS; 1: never (workspace + transposes, or generic strides).
  * key 1: dynamic LDS bytes requested per sim_ahead workgroup (the kernels use no LDS; this only caps the
  *        number of resident workgroups per CU for occupancy experiments; 0 = none).
  * Returns the previous value, or EXCENV_EINVAL for an unknown key. */
