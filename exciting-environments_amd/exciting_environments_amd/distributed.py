@@ -25,6 +25,37 @@ def shard_sizes(global_batch: int, world_size: int):
             for r in range(world_size)]
 
 
+def _slice_leaf(v, global_batch, lo, hi):
+    import numpy as np
+
+    if isinstance(v, (torch.Tensor, np.ndarray)) and v.ndim >= 1 and v.shape[0] == global_batch:
+        return v[lo:hi]
+    return v
+
+
+def make_sharded_env(env_type, global_batch_size: int, group: Optional[dist.ProcessGroup] = None, rank: Optional[int] = None,
+                     world_size: Optional[int] = None, **env_kwargs):
+    """Build THIS rank's environment over its contiguous slice of a global batch: `batch_size` becomes the shard size
+    and every property leaf given as a [global_batch_size] array (static_params values, MinMaxNormalization.min / .max) is
+    sliced to the shard. Returns (env, (start, stop)). `env_type` is an EnvironmentRegistry member."""
+    from .utils import MinMaxNormalization
+
+    if world_size is None:
+        world_size = dist.get_world_size(group)
+    if rank is None:
+        rank = dist.get_rank(group)
+    lo, hi = shard_range(global_batch_size, world_size, rank)
+    kw = dict(env_kwargs)
+    if kw.get("static_params"):
+        kw["static_params"] = {k: _slice_leaf(v, global_batch_size, lo, hi) for k, v in kw["static_params"].items()}
+    for name in ("physical_normalizations", "action_normalizations"):
+        if kw.get(name):
+            kw[name] = {k: MinMaxNormalization(min=_slice_leaf(n.min, global_batch_size, lo, hi),
+                                               max=_slice_leaf(n.max, global_batch_size, lo, hi)) for k, n in kw[name].items()}
+    kw["batch_size"] = hi - lo
+    return env_type.make(**kw), (lo, hi)
+
+
 class ObservationGatherer:
     """All-gather of per-rank observation shards [B_r, ...] into the global [B, ...] array on every rank.
 

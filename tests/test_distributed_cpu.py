@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from exciting_environments_amd.distributed import ObservationGatherer, shard_range, shard_sizes
+from exciting_environments_amd.distributed import ObservationGatherer, make_sharded_env, shard_range, shard_sizes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -26,6 +26,23 @@ def test_shard_ranges_partition_the_batch():
     assert shard_range(2**25, 8, 3) == (3 * 2**22, 4 * 2**22)
     with pytest.raises(ValueError):
         shard_range(8, 2, 2)
+
+
+def test_make_sharded_env_slices_per_env_properties():
+    from exciting_environments_amd import EnvironmentRegistry, MinMaxNormalization
+
+    B = 10
+    l = np.linspace(1.0, 2.0, B)
+    tmin = torch.linspace(-20, -11, B)
+    envs = [make_sharded_env(EnvironmentRegistry.PENDULUM, B, rank=r, world_size=3, device="cpu",
+                             static_params={"g": 9.81, "l": l, "m": 1},
+                             action_normalizations={"torque": MinMaxNormalization(min=tmin, max=20)}) for r in range(3)]
+    assert [e.batch_size for e, _ in envs] == [4, 3, 3] and [rng for _, rng in envs] == [(0, 4), (4, 7), (7, 10)]
+    assert np.array_equal(np.concatenate([e.env_properties.static_params.l for e, _ in envs]), l)
+    assert torch.equal(torch.cat([e.env_properties.action_normalizations.torque.min for e, _ in envs]), tmin)
+    assert all(e.env_properties.static_params.g == 9.81 and e.in_axes_env_properties.static_params.l == 0 for e, _ in envs)
+    obs, state = envs[1][0].vmap_reset()
+    assert obs.shape == (3, 2)
 
 
 def _free_port():
