@@ -13,7 +13,7 @@
  * otherwise; excenv_last_error() gives the per-thread message.
  *
  * Data layout (struct-of-arrays): every state field / per-env parameter is its
- * own contiguous [B] array. Trajectories come in two layouts:
+ * own contiguous [B] array. Trajectories come in three layouts:
  *   EXCENV_LAYOUT_ENV_MAJOR  : element (b,k,c) at ((b*K)+k)*C + c  — the reference's
  *                              row-major jnp arrays actions[B,K,A], observations[B,K+1,O],
  *                              state leaves [B,K+1] (core_env.py:571-616).
