@@ -9,8 +9,10 @@ every step reuses) are resident in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1: launched by torch.distributed.run, one rank per GPU, batch sharded (weak scaling: 2^22 envs per rank),
-no collective on the stepping path; the observations are reassembled with ONE RCCL all-gather of the final
+N > 1: one rank per GPU, batch sharded (weak scaling: 2^22 envs per rank), no collective on the stepping path. Either
+launched by torch.distributed.run (WORLD_SIZE / RANK / LOCAL_RANK in the environment) or invoked directly — then this
+process, before touching any GPU, starts the N ranks itself as child processes (torch.distributed.run) and forwards
+their output and exit code; the observations are reassembled with ONE RCCL all-gather of the final
 observation row at the end of the timed region (`--gather chunk`: after every chunk on a side stream, overlapped;
 `--gather none`: never).
 Rank 0 prints ONE JSON line.
@@ -171,7 +173,7 @@ def cpu_baseline(args, reg, solver, dtype, tau, Kc):
     }
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -194,14 +196,43 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="env-major buffers: do not use the fused LDS time-tile kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) invoked directly: THIS process has not touched the GPU and never will — it starts
+    one child process per GPU through torch.distributed.run (fresh interpreters, no exec of a GPU-initialised process),
+    forwards their output (rank 0 prints the JSON line) and exits with the launcher's code."""
+    import socket
+    import subprocess
+
+    one_gpu = os.environ.get("EXCENV_BENCH_ONE_GPU") == "1"
+    have = torch.cuda.device_count()  # does not initialise the HIP runtime
+    if have < args.gpus and not one_gpu:
+        sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible "
+                 "(rehearsal on one GPU: EXCENV_BENCH_ONE_GPU=1 EXCENV_BENCH_BACKEND=gloo)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        launch_ranks(args)  # never returns
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: WORLD_SIZE={world} does not match --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # rehearsal knobs (single-GPU box): EXCENV_BENCH_ONE_GPU=1 puts every rank on GPU 0, EXCENV_BENCH_BACKEND=gloo
     # replaces RCCL (which refuses two ranks on one device). The driver's multi-GPU runs use neither.
@@ -221,15 +252,16 @@ def main():
     from exciting_environments_amd.distributed import ObservationGatherer
 
     env, state, actions, B, Kc, reg, solver, dtype = build_env(args, device, rank)
-    if args.vec:
-        _native.set_tuning(0, args.vec)
-    if args.lds_pad:
-        _native.set_tuning(1, args.lds_pad)
+    if args.vec or args.lds_pad:
+        env.launch_opts = _native.launch_opts(envs_per_lane=args.vec, lds_pad_bytes=args.lds_pad)
     use_gather = args.gather != "none" and (world > 1 or os.environ.get("EXCENV_BENCH_FORCE_GATHER") == "1")
     if use_gather and not dist.is_initialized():  # 1-rank rehearsal of the collective path
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": device} if backend == "nccl" else {}))
+    ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
+    if ranks_seen != world:
+        sys.exit(f"bench.py: the process group reports {ranks_seen} ranks, expected {world}")
     gatherer = ObservationGatherer(B * world) if use_gather else None
     gathered = None
 
@@ -290,8 +322,11 @@ def main():
         elapsed = float(t.item())
 
     finite = bool(torch.isfinite(state.physical_state.__dict__[env.STATE_FIELDS[-1]]).all())
-    # events bracket the launch on the launch stream; with the gather enabled the bracket also holds the
-    # (asynchronous) enqueue of the collective but no wait for it
+    gather_ok = None
+    if gathered is not None and last_obs[0] is not None:  # this rank's slice of the gathered batch is its own final row
+        gather_ok = bool(torch.equal(gathered[rank * B:(rank + 1) * B], final_row(last_obs[0])))
+    # HIP events on the launch stream (torch's current stream is the stream the C ABI is handed); with the gather enabled
+    # the bracket also holds the (asynchronous) enqueue of the collective but no wait for it
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
     if args.path == "step":
         Kc = 1
@@ -301,7 +336,9 @@ def main():
     algo_bytes = bytes_per_step * B * Kc
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if args.steps else float("nan")
 
-    traffic = None
+    # HBM traffic per launch from the PMC counters cannot be collected inside this process: it is REPLAYED from the
+    # committed rocprofv3 --pmc passes (tools/traffic_probe.py -> profiles/traffic.json) for the same workload key
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
@@ -309,6 +346,7 @@ def main():
             key = f"{args.workload}|B={B}|chunk={Kc}|{args.traj_layout}" + ("|step" if args.path == "step" else "")
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
+                traffic_source = "replayed from profiles/traffic.json (" + tj[key].get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes") + "), not measured in this run"
         except Exception:
             traffic = None
 
@@ -337,11 +375,15 @@ def main():
                 "parallelism": f"batch-sharded x{world}" + (
                     "" if gatherer is None else (", one all-gather of the final observations at the end" if args.gather == "end"
                                                  else ", all-gather(final obs) after every chunk, overlapped")),
+                "ranks_seen": ranks_seen,
+                "backend": (dist.get_backend() if dist.is_initialized() else None),
+                "collective": (gatherer.collective if gatherer is not None else None),
+                "gathered_slice_matches_local": gather_ok,
                 "outputs_finite": finite,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "sim_ahead_kernel" if args.path == "sim_ahead" else "step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_step,
                 "algorithmic_bytes_per_launch": algo_bytes, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },

@@ -52,9 +52,17 @@ static const EnvVTable* table_for(int env, const excenv_props_t* props, int* rc)
   return table(env);
 }
 
-static int g_vec_pref = 0;
-static int g_lds_pad = 0;
-static int g_em_mode = 0;
+static const excenv_launch_opts_t kDefaultOpts = {0, 0, 0, 0};
+
+static int check_opts(const char* fn, const excenv_launch_opts_t*& o) {
+  if (!o) o = &kDefaultOpts;
+  const int v = o->envs_per_lane;
+  if (!(v == 0 || v == 1 || v == 2 || v == 4)) { set_error("%s: opts.envs_per_lane must be 0, 1, 2 or 4 (got %d)", fn, v); return EXCENV_EINVAL; }
+  if (o->env_major_mode != 0 && o->env_major_mode != 1) { set_error("%s: opts.env_major_mode must be 0 or 1", fn); return EXCENV_EINVAL; }
+  if (o->lds_pad_bytes < 0 || o->lds_pad_bytes > 150 * 1024) { set_error("%s: opts.lds_pad_bytes out of range", fn); return EXCENV_EINVAL; }
+  if (o->reserved != 0) { set_error("%s: opts.reserved must be 0", fn); return EXCENV_EINVAL; }
+  return EXCENV_OK;
+}
 
 static int check_common(const char* fn, int env, int solver, int dtype, int64_t B) {
   if (env < 0 || env >= EXCENV_NUM_ENVS) { set_error("%s: bad env id %d", fn, env); return EXCENV_EINVAL; }
@@ -109,22 +117,14 @@ int64_t excenv_sim_ahead_bytes(int env, int dtype, int with_state_traj) {
   return w * (t->A + t->O + (with_state_traj ? t->S : 0));
 }
 
-/* tuning knob (not part of the reference surface): key 0 = envs per lane for lane-major trajectories
- * (0 auto, 1/2/4 forced). Returns the previous value. */
-int excenv_set_tuning(int key, int value) {
-  if (key == 0) { int old = g_vec_pref; g_vec_pref = value; return old; }
-  if (key == 1) { int old = g_lds_pad; g_lds_pad = value < 0 ? 0 : value; return old; }
-  if (key == 2) { int old = g_em_mode; g_em_mode = value; return old; }
-  return EXCENV_EINVAL;
-}
-
 int excenv_step(int env, int solver, int dtype, int64_t B, const excenv_props_t* props,
                 const excenv_control_t* control, double tau, const void* const* state_in, const void* action,
-                void* const* state_out, void* obs, void* stream) {
+                void* const* state_out, void* obs, const excenv_launch_opts_t* opts, void* stream) {
   if (int rc = check_common("excenv_step", env, solver, dtype, B)) return rc;
   if (!props || !state_in || !action || !state_out || !obs) { set_error("excenv_step: NULL argument"); return EXCENV_ENULL; }
   if (int rc = check_control("excenv_step", env, control)) return rc;
-  StepCall sc{g_vec_pref, solver, dtype, B, props, control, tau, state_in, action, state_out, obs, nullptr, nullptr, nullptr,
+  if (int rc = check_opts("excenv_step", opts)) return rc;
+  StepCall sc{opts->envs_per_lane, solver, dtype, B, props, control, tau, state_in, action, state_out, obs, nullptr, nullptr, nullptr,
               (hipStream_t)stream};
   int rc;
   const EnvVTable* vt = table_for(env, props, &rc);
@@ -140,13 +140,14 @@ int32_t excenv_truncated_width(int env, int32_t n_control) {
 int excenv_gym_step(int env, int solver, int dtype, int64_t B, const excenv_props_t* props,
                     const excenv_control_t* control, double tau, const void* const* state_in, const void* action,
                     void* const* state_out, void* obs, void* reward, uint8_t* terminated, uint8_t* truncated,
-                    void* stream) {
+                    const excenv_launch_opts_t* opts, void* stream) {
   if (int rc = check_common("excenv_gym_step", env, solver, dtype, B)) return rc;
   if (!props || !state_in || !action || !state_out || !obs || !reward || !terminated || !truncated) {
     set_error("excenv_gym_step: NULL argument");
     return EXCENV_ENULL;
   }
   if (int rc = check_control("excenv_gym_step", env, control)) return rc;
+  if (int rc = check_opts("excenv_gym_step", opts)) return rc;
   StepCall sc{1, solver, dtype, B, props, control, tau, state_in, action, state_out, obs, reward, terminated, truncated,
               (hipStream_t)stream};
   int rc;
@@ -182,7 +183,8 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
                         const excenv_props_t* props, const excenv_control_t* control, double obs_stepsize,
                         double env_tau, const void* const* state_in, const void* actions, int action_layout,
                         void* obs_traj, void* const* state_traj, int traj_layout, void* const* last_state,
-                        int semantics, void* workspace, int64_t workspace_bytes, void* stream) {
+                        int semantics, const excenv_traj_gym_t* gym, void* workspace, int64_t workspace_bytes,
+                        const excenv_launch_opts_t* opts, void* stream) {
   if (int rc = check_common("excenv_sim_ahead", env, solver, dtype, B)) return rc;
   if (K < 0 || substeps < 1) { set_error("excenv_sim_ahead: bad K=%lld or substeps=%d", (long long)K, substeps); return EXCENV_EINVAL; }
   if (semantics != EXCENV_SEM_STEP && semantics != EXCENV_SEM_AHEAD) { set_error("excenv_sim_ahead: bad semantics %d", semantics); return EXCENV_EINVAL; }
@@ -193,25 +195,29 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
   }
   if (!props || !state_in || (!actions && K > 0) || !obs_traj || !last_state) { set_error("excenv_sim_ahead: NULL argument"); return EXCENV_ENULL; }
   if (int rc = check_control("excenv_sim_ahead", env, control)) return rc;
+  if (int rc = check_opts("excenv_sim_ahead", opts)) return rc;
   int trc;
   const EnvVTable* t = table_for(env, props, &trc);
   if (!t) return trc;
   const int nc = control ? control->n_control : 0;
+  const int64_t wbytes = dtype == EXCENV_F64 ? 8 : 4;
+  // one decision for the whole call: fused env-major kernel / workspace + transposes / generic strides
+  const bool fused_em = B > 0 && K > 0 && aligned16(obs_traj) &&
+                        em_fused_eligible(opts->env_major_mode, action_layout, traj_layout, substeps, gym != nullptr, t->A,
+                                          t->O + nc, t->S, state_traj != nullptr, (size_t)wbytes);
   const int64_t need = excenv_sim_ahead_workspace_bytes(env, dtype, B, K, substeps, nc, action_layout, traj_layout,
                                                         state_traj != nullptr);
-  const int64_t wbytes = dtype == EXCENV_F64 ? 8 : 4;
-  const bool fused_em = g_em_mode != 1 && action_layout == EXCENV_LAYOUT_ENV_MAJOR && traj_layout == EXCENV_LAYOUT_ENV_MAJOR &&
-                        substeps == 1 &&
-                        (int64_t)em_lds_elems<float>(t->A, t->O + nc, t->S, state_traj != nullptr) * wbytes <= 150 * 1024;
-  const bool via_ws = !fused_em && workspace && need > 0 && workspace_bytes >= need && B > 0 &&
+  const bool via_ws = !fused_em && !gym && workspace && need > 0 && workspace_bytes >= need && B > 0 &&
                       (action_layout == EXCENV_LAYOUT_ENV_MAJOR || traj_layout == EXCENV_LAYOUT_ENV_MAJOR);
+  const int em = fused_em ? 2 : 1;
   if (!via_ws) {
     SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, actions, action_layout,
-               obs_traj, state_traj, traj_layout, last_state, semantics, g_vec_pref, g_lds_pad, g_em_mode, (hipStream_t)stream};
+               obs_traj, state_traj, traj_layout, last_state, semantics, opts->envs_per_lane, opts->lds_pad_bytes, em, gym,
+               (hipStream_t)stream};
     return t->sim(sc);
   }
   // env-major buffers + workspace: transpose in, run the coalesced lane-major kernel, transpose out
-  const int64_t w = dtype == EXCENV_F64 ? 8 : 4, N = K * substeps, OW = t->O + nc;
+  const int64_t w = wbytes, N = K * substeps, OW = t->O + nc;
   char* ws = (char*)workspace;
   const void* k_actions = actions;
   int k_alayout = action_layout, k_tlayout = traj_layout;
@@ -235,7 +241,7 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
     k_tlayout = EXCENV_LAYOUT_LANE_MAJOR;
   }
   SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, k_actions, k_alayout,
-             k_obs, k_straj_p, k_tlayout, last_state, semantics, g_vec_pref, g_lds_pad, g_em_mode, st};
+             k_obs, k_straj_p, k_tlayout, last_state, semantics, opts->envs_per_lane, opts->lds_pad_bytes, 1, nullptr, st};
   if (int rc = t->sim(sc)) return rc;
   if (traj_layout == EXCENV_LAYOUT_ENV_MAJOR) {
     if (int rc = launch_transpose(dtype, (N + 1) * OW, B, k_obs, obs_traj, st)) { set_error("excenv_sim_ahead: obs transpose failed"); return rc; }
@@ -250,9 +256,10 @@ int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
                      const excenv_props_t* props, const excenv_control_t* control, double obs_stepsize,
                      double env_tau, const void* const* state_in, const void* actions, int action_layout,
                      void* obs_traj, void* const* state_traj, int traj_layout, void* const* last_state,
-                     int semantics, void* stream) {
+                     int semantics, const excenv_traj_gym_t* gym, const excenv_launch_opts_t* opts, void* stream) {
   return excenv_sim_ahead_ws(env, solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, actions,
-                             action_layout, obs_traj, state_traj, traj_layout, last_state, semantics, nullptr, 0, stream);
+                             action_layout, obs_traj, state_traj, traj_layout, last_state, semantics, gym, nullptr, 0, opts,
+                             stream);
 }
 
 int excenv_probe_math(int which, int dtype, int64_t n, const void* in, void* out, void* stream) {

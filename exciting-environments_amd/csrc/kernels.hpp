@@ -12,6 +12,9 @@ namespace excenv {
 #ifndef EXCENV_NT_STORES
 #define EXCENV_NT_STORES 1
 #endif
+#ifndef EXCENV_PINGPONG
+#define EXCENV_PINGPONG 1  // bit 0: Euler, bit 1: RK4 / Tsit5 — K loop unrolled by two with ping-pong action registers
+#endif                      // (2-step prefetch distance, 2x loop code). Measured: +3.5 % Euler, -5 % Tsit5.
 constexpr int BLOCK = EXCENV_BLOCK;
 
 // Property leaves in kernel-argument order: P statics, S mins, S maxs, A mins, A maxs.
@@ -61,6 +64,12 @@ template <typename T, class M> struct SimArgs {
   int32_t control_idx[EXCENV_MAX_CONTROL];
   const T* reference[EXCENV_MAX_CONTROL];
   T dt, env_tau, adv_coef;
+  // optional gym trajectories (all three or none; GENERAL instantiation): reward / terminated hold rows 1..N at step
+  // index n-1 with element strides (g_sb, g_sk); truncated holds rows 0..N with strides (t_sb, t_sk, t_sc)
+  T* reward;
+  uint8_t* terminated;
+  uint8_t* truncated;
+  int64_t g_sb, g_sk, t_sb, t_sk, t_sc;
 };
 
 template <bool BATCHED, typename T, class M>
@@ -188,18 +197,53 @@ template <typename T, int N> __device__ __forceinline__ void load_row(const T* s
   }
 }
 
+// ---- gym outputs of one saved state (generate_reward / generate_terminated / generate_truncated) ----------------
+// `ob` is the observation row of `st` (without control columns); `ref[j]` the physical reference of control column j.
+// Stores through the three element pointers (reward, terminated: one element; truncated: TW flags, stride t_sc).
+template <class M, typename T>
+__device__ __forceinline__ void gym_outputs(const T (&st)[M::S], const T (&ob)[M::O], const Ctx<T, M>& c, int n_control,
+                                            const int* idx, const T (&ref)[EXCENV_MAX_CONTROL], T* reward, uint8_t* terminated,
+                                            uint8_t* truncated, int64_t t_sc) {
+  const T rew = (reward != nullptr) ? env_reward<M, T>(st, c, n_control, idx, ref) : T(0);
+  if (reward != nullptr) *reward = rew;
+  if constexpr (M::IS_PMSM) {  // pmsm_env.py:972-983: |i_dq_norm| > 1, terminated == truncated
+    const T nd = normalize(st[3], c.smin[3], c.smax[3]), nq = normalize(st[4], c.smin[4], c.smax[4]);
+    const uint8_t t = xsqrt(nd * nd + nq * nq) > T(1);
+    if (truncated != nullptr) truncated[0] = t;
+    if (terminated != nullptr) *terminated = t;
+  } else if constexpr (M::ID == EXCENV_FLUID_TANK) {  // fluid_tank_env.py:325-333: constants
+    if (truncated != nullptr) truncated[0] = 0;
+    if (terminated != nullptr) *terminated = 0;
+  } else {  // truncated = |obs| > 1 over every observation column, terminated = (reward == 0)
+    if (truncated != nullptr) {
+#pragma unroll
+      for (int q = 0; q < M::O; ++q) truncated[q * t_sc] = xabs(ob[q]) > T(1);
+#pragma unroll
+      for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+        if (j < n_control) {
+          T x, lo, hi;
+          pick_field<M, T>(st, c, idx[j], x, lo, hi);
+          truncated[(M::O + j) * t_sc] = xabs(normalize(ref[j], lo, hi)) > T(1);
+        }
+      }
+    }
+    if (terminated != nullptr) *terminated = rew == T(0);
+  }
+}
+
 // ---- vmap_step: one fused launch (reference core_env.py:533-569) ---------------------------
-// V adjacent envs per lane (V > 1 only without batched properties / control columns): [B] state arrays move as
-// 16-byte vectors, the row-major action / obs rows of the V envs are one contiguous run of V*A / V*O words.
-template <class M, typename T, int SOLVER, bool BATCHED, int V>
+// V adjacent envs per lane (V > 1 only in the non-GENERAL instantiations): [B] state arrays move as 16-byte vectors, the
+// row-major action / obs rows of the V envs are one contiguous run of V*A / V*O words. GENERAL (V == 1): per-env property
+// arrays, reference-tracking observation columns and the optional fused gym outputs.
+template <class M, typename T, int SOLVER, bool GENERAL, int V>
 __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
-  static_assert(!(BATCHED && V > 1), "vectorised lanes share one uniform property set");
+  static_assert(!(GENERAL && V > 1), "vectorised lanes share one uniform property set");
   const int64_t blk0 = (int64_t)blockIdx.x * (BLOCK * V);
   const unsigned lane_env = threadIdx.x * V;
   const int64_t i = blk0 + lane_env;
   Ctx<T, M> c;
-  load_ctx<BATCHED>(c, ka.kp, (i < ka.B) ? i : 0, ka.dt, ka.env_tau, ka.adv_coef);
+  load_ctx<GENERAL>(c, ka.kp, (i < ka.B) ? i : 0, ka.dt, ka.env_tau, ka.adv_coef);
   stage_lut<M, T>(c, ka.kp);
   if (i >= ka.B) return;
   T st[V][S], a[V * A], ob[V * O];
@@ -228,67 +272,55 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
     for (int v = 0; v < V; ++v) tmp[v] = st[v][j];
     store_v<T, V>(ka.state_out[j] + blk0 + lane_env, tmp);
   }
-  if (ka.n_control == 0) {
+  if constexpr (!GENERAL) {
     store_row<T, V * O>(ka.obs + blk0 * O + lane_env * O, ob);
-  } else {  // V == 1 here (host)
-    T* row = ka.obs + i * (O + ka.n_control);
+  } else {
+    T rref[EXCENV_MAX_CONTROL];
 #pragma unroll
-    for (int j = 0; j < O; ++j) row[j] = ob[j];
-    for (int j = 0; j < ka.n_control; ++j) {
-      const int f = ka.control_idx[j];
-      const T r = ka.reference[j][i];
-      T lo = c.smin[0], hi = c.smax[0];
+    for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) rref[j] = (j < ka.n_control) ? ka.reference[j][i] : T(0);
+    if (ka.n_control == 0) {
+      store_row<T, O>(ka.obs + i * O, ob);
+    } else {
+      T* row = ka.obs + i * (O + ka.n_control);
 #pragma unroll
-      for (int q = 1; q < S; ++q) {
-        lo = (f == q) ? c.smin[q] : lo;
-        hi = (f == q) ? c.smax[q] : hi;
-      }
-      row[O + j] = normalize(r, lo, hi);
-    }
-  }
-  if constexpr (V == 1) {
-    if (ka.reward != nullptr) {  // GymWrapper.gym_step (gym_wrapper.py:117-126), fused: no second pass over the state
-      T refs[EXCENV_MAX_CONTROL];
-      for (int j = 0; j < ka.n_control; ++j) refs[j] = ka.reference[j][i];
-      const T rew = env_reward<M, T>(st[0], c, ka.n_control, ka.control_idx, refs);
-      ka.reward[i] = rew;
-      if constexpr (M::IS_PMSM) {  // pmsm_env.py:972-983: |i_dq_norm| > 1, terminated == truncated
-        const T nd = normalize(st[0][3], c.smin[3], c.smax[3]), nq = normalize(st[0][4], c.smin[4], c.smax[4]);
-        const uint8_t t = xsqrt(nd * nd + nq * nq) > T(1);
-        ka.truncated[i] = t;
-        ka.terminated[i] = t;
-      } else if constexpr (M::ID == EXCENV_FLUID_TANK) {  // fluid_tank_env.py:325-333: constants
-        ka.truncated[i] = 0;
-        ka.terminated[i] = 0;
-      } else {  // truncated = |obs| > 1 over every observation column, terminated = (reward == 0)
-        const int OW = O + ka.n_control;
-        uint8_t* trow = ka.truncated + i * OW;
+      for (int j = 0; j < O; ++j) row[j] = ob[j];
 #pragma unroll
-        for (int q = 0; q < O; ++q) trow[q] = xabs(ob[q]) > T(1);
-        for (int j = 0; j < ka.n_control; ++j) {
+      for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+        if (j < ka.n_control) {
           T x, lo, hi;
           pick_field<M, T>(st[0], c, ka.control_idx[j], x, lo, hi);
-          trow[O + j] = xabs(normalize(refs[j], lo, hi)) > T(1);
+          row[O + j] = normalize(rref[j], lo, hi);
         }
-        ka.terminated[i] = rew == T(0);
       }
+    }
+    if (ka.reward != nullptr) {  // GymWrapper.gym_step (gym_wrapper.py:117-126), fused: no second pass over the state
+      const int64_t tw = (M::IS_PMSM || M::ID == EXCENV_FLUID_TANK) ? 1 : O + ka.n_control;
+      gym_outputs<M, T>(st[0], ob, c, ka.n_control, ka.control_idx, rref, ka.reward + i, ka.terminated + i,
+                        ka.truncated + i * tw, 1);
     }
   }
 }
 
 // ---- vmap_sim_ahead: one persistent launch for all N = K*substeps solver steps ------------------
 // (reference core_env.py:571-616 + each env's _ode_solver_simulate_ahead; PMSM.sim_ahead pmsm_env.py:746-801)
-template <class M, typename T, int SOLVER, bool AHEAD, bool BATCHED, int V>
+//
+// GENERAL instantiation (V == 1): per-env property arrays, reference-tracking observation columns and the optional
+// reward / terminated / truncated trajectories (core_env.py:490-531). The other instantiations assume broadcast
+// properties and no control columns (the host routes accordingly).
+//
+// Pipeline: the action rows ping-pong between two register sets (component-major, so a 16-byte load lands in place);
+// the row of solver step n+1 is requested before row n is saved and step n is computed, and is first read one whole step
+// later (Euler) or in the last RK stage of step n (c_i == 1 stages see action k+1) — its s_waitcnt therefore sits after a
+// compute phase and never has to drain the trajectory stores issued in between (vmcnt counts loads and stores in order).
+template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V>
 __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
-  static_assert(!(BATCHED && V > 1), "vectorised lanes share one uniform property set");
-  // Addressing: every access is (wave-uniform base, kept in SGPRs) + (small unsigned per-lane offset),
-  // so one VGPR of offset serves all 2*S + A + O streams (global_* saddr form).
+  static_assert(!(GENERAL && V > 1), "vectorised lanes share one uniform property set");
   const int64_t blk0 = (int64_t)blockIdx.x * (BLOCK * V);  // first env of this workgroup
   const unsigned lane_env = threadIdx.x * V;
   const int64_t i0 = blk0 + lane_env;
   Ctx<T, M> c;
-  load_ctx<BATCHED>(c, ka.kp, (i0 < ka.B) ? i0 : 0, ka.dt, ka.env_tau, ka.adv_coef);
+  load_ctx<GENERAL>(c, ka.kp, (i0 < ka.B) ? i0 : 0, ka.dt, ka.env_tau, ka.adv_coef);
   stage_lut<M, T>(c, ka.kp);
   if (i0 >= ka.B) return;  // host guarantees B % V == 0
 
@@ -311,6 +343,27 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   }
   const bool deadtime_on = (M::IS_PMSM) ? (c.P[M::P - 1] > T(0)) : false;
 
+  // reference-tracking columns: constant along the trajectory, loaded and normalised once (static register indices)
+  T rref[EXCENV_MAX_CONTROL], cref[EXCENV_MAX_CONTROL];
+  if constexpr (GENERAL) {
+#pragma unroll
+    for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+      rref[j] = T(0);
+      cref[j] = T(0);
+      if (j < ka.n_control) {
+        const int f = ka.control_idx[j];
+        T lo = c.smin[0], hi = c.smax[0];
+#pragma unroll
+        for (int q = 1; q < S; ++q) {
+          lo = (f == q) ? c.smin[q] : lo;
+          hi = (f == q) ? c.smax[q] : hi;
+        }
+        rref[j] = ka.reference[j][i0];
+        cref[j] = normalize(rref[j], lo, hi);
+      }
+    }
+  }
+
   const int64_t N = ka.K * ka.substeps;
   // V > 1 implies env stride 1; for V == 1 the host has checked that 256 * stride * sizeof(T) < 2^31
   const T* a_blk = ka.actions + (int64_t)blockIdx.x * ka.a_wg;
@@ -321,31 +374,8 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   const unsigned s_lane = (V == 1) ? threadIdx.x * (unsigned)ka.s_sb : lane_env;
   const bool with_states = ka.straj[0] != nullptr;
 
-  T a_cur[V][A], a_nxt[V][A];
-  auto load_action = [&](int64_t k, T (&dst)[V][A]) {
-#pragma unroll
-    for (int q = 0; q < A; ++q) {
-      T tmp[V];
-      const T* row = a_blk + k * ka.a_sk + q * ka.a_sc;
-      load_v<T, V>(row + a_lane, tmp);
-#pragma unroll
-      for (int v = 0; v < V; ++v) dst[v][q] = tmp[v];
-    }
-  };
-  if (N > 0) load_action(0, a_cur);
-
-  int64_t k = 0;
-  int32_t sub = 0;
-  for (int64_t n = 0;; ++n) {
-    // action row of solver step n+1, requested a whole step ahead of its use
-    int64_t kn = k;
-    int32_t subn = sub + 1;
-    if (subn == ka.substeps) { subn = 0; kn = k + 1; }
-    const int64_t k1 = (kn < ka.K) ? kn : ka.K - 1;
-    if (n < N) load_action(k1, a_nxt);
-
-    // ---- save row n ----
-    T sv[V][S];
+  // ---- save row n: observation, (control columns), state leaves, (gym outputs); returns the saved state in sv ----
+  auto save_row = [&](int64_t n, T (&sv)[V][S]) {
 #pragma unroll
     for (int v = 0; v < V; ++v) {
 #pragma unroll
@@ -363,70 +393,131 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
         }
       }
     }
-    {
-      T ob[V][O];
+    T ob[V][O];
 #pragma unroll
-      for (int v = 0; v < V; ++v) M::observe(sv[v], c, ob[v]);
-      T* orow = o_blk + n * ka.o_sk;
+    for (int v = 0; v < V; ++v) M::observe(sv[v], c, ob[v]);
+    T* orow = o_blk + n * ka.o_sk;
 #pragma unroll
-      for (int q = 0; q < O; ++q) {
-        T tmp[V];
+    for (int q = 0; q < O; ++q) {
+      T tmp[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) tmp[v] = ob[v][q];
-        store_stream<T, V>(orow + q * ka.o_sc + o_lane, tmp);
-      }
-      if (ka.n_control > 0) {  // reference-tracking columns (constant along the trajectory)
-        for (int j = 0; j < ka.n_control; ++j) {
-          const int f = ka.control_idx[j];
-          T lo = c.smin[0], hi = c.smax[0];
-#pragma unroll
-          for (int q = 1; q < S; ++q) {
-            lo = (f == q) ? c.smin[q] : lo;
-            hi = (f == q) ? c.smax[q] : hi;
-          }
-          T tmp[V];
-#pragma unroll
-          for (int v = 0; v < V; ++v) tmp[v] = normalize(ka.reference[j][i0 + v], lo, hi);
-          store_v<T, V>(orow + (O + j) * ka.o_sc + o_lane, tmp);
-        }
-      }
-      if (with_states) {
-#pragma unroll
-        for (int j = 0; j < S; ++j) {
-          T tmp[V];
-#pragma unroll
-          for (int v = 0; v < V; ++v) tmp[v] = sv[v][j];
-          store_stream<T, V>(ka.straj[j] + s_blk + n * ka.s_sk + s_lane, tmp);
-        }
-      }
+      for (int v = 0; v < V; ++v) tmp[v] = ob[v][q];
+      store_stream<T, V>(orow + q * ka.o_sc + o_lane, tmp);
     }
-    if (n == N) {
+    if constexpr (GENERAL) {
+#pragma unroll
+      for (int j = 0; j < EXCENV_MAX_CONTROL; ++j)
+        if (j < ka.n_control) orow[(O + j) * ka.o_sc + o_lane] = cref[j];
+    }
+    if (with_states) {
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         T tmp[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) tmp[v] = sv[v][j];
-        store_v<T, V>(ka.last_state[j] + blk0 + lane_env, tmp);
+        store_stream<T, V>(ka.straj[j] + s_blk + n * ka.s_sk + s_lane, tmp);
       }
-      break;
     }
+    if constexpr (GENERAL) {  // core_env.py:490-531: truncated on every row, reward / terminated on rows 1..N
+      if (ka.truncated != nullptr) {
+        const int64_t e = i0;
+        uint8_t* tr = ka.truncated + e * ka.t_sb + n * ka.t_sk;
+        const bool tail = n > 0;
+        T* rw = tail ? ka.reward + e * ka.g_sb + (n - 1) * ka.g_sk : nullptr;
+        uint8_t* te = tail ? ka.terminated + e * ka.g_sb + (n - 1) * ka.g_sk : nullptr;
+        gym_outputs<M, T>(sv[0], ob[0], c, ka.n_control, ka.control_idx, rref, rw, te, tr, ka.t_sc);
+      }
+    }
+  };
+  auto publish_last = [&](const T (&sv)[V][S]) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      T tmp[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) tmp[v] = sv[v][j];
+      store_v<T, V>(ka.last_state[j] + blk0 + lane_env, tmp);
+    }
+  };
+  T sv[V][S];
+  if (N == 0) {  // no action row exists (ka.actions may be NULL)
+    save_row(0, sv);
+    publish_last(sv);
+    return;
+  }
 
-    // ---- advance one solver step ----
+  T a0[A][V], a1[A][V];
+  auto load_action = [&](int64_t krow, T (&dst)[A][V]) {
+#pragma unroll
+    for (int q = 0; q < A; ++q) load_v<T, V>(a_blk + krow * ka.a_sk + q * ka.a_sc + a_lane, dst[q]);
+  };
+  auto advance = [&](const T (&cur)[A][V], const T (&nxt)[A][V], int64_t k, int64_t k1) {
 #pragma unroll
     for (int v = 0; v < V; ++v) {
+      T ac[A], an[A];
+#pragma unroll
+      for (int q = 0; q < A; ++q) {
+        ac[q] = cur[q][v];
+        an[q] = nxt[q][v];
+      }
       if constexpr (AHEAD) {
-        env_advance_raw<M, SOLVER>(st[v], a_cur[v], a_nxt[v], k, k1, c, aux[v]);
+        env_advance_raw<M, SOLVER>(st[v], ac, an, k, k1, c, aux[v]);
       } else {
-        env_step<M, SOLVER>(st[v], a_cur[v], c);
+        env_step<M, SOLVER>(st[v], ac, c);
       }
     }
+  };
+  // (k, sub): action row and sub-step of solver step n; (kn, subn): those of step n + 1
+  int64_t k = 0, kn;
+  int32_t sub = 0, subn;
+  auto next_index = [&]() {
+    kn = k;
+    subn = sub + 1;
+    if (subn == ka.substeps) { subn = 0; kn = k + 1; }
+  };
+  const int64_t klast = ka.K - 1;
+  load_action(0, a0);
+  constexpr bool PINGPONG = ((SOLVER == EXCENV_EULER) ? (EXCENV_PINGPONG & 1) : (EXCENV_PINGPONG & 2)) != 0;
+  if constexpr (PINGPONG) {
+    for (int64_t n = 0;; n += 2) {
+      // even step: a0 holds action row k; the row of step n + 1 goes to a1 (clamped: always a valid row, so the load is
+      // unconditional and its result needs no merge with an undefined value)
+      next_index();
+      int64_t k1 = (kn < klast) ? kn : klast;
+      load_action(k1, a1);
+      save_row(n, sv);
+      if (n == N) break;
+      advance(a0, a1, k, k1);
+      k = kn;
+      sub = subn;
+      // odd step: roles swapped
+      next_index();
+      k1 = (kn < klast) ? kn : klast;
+      load_action(k1, a0);
+      save_row(n + 1, sv);
+      if (n + 1 == N) break;
+      advance(a1, a0, k, k1);
+      k = kn;
+      sub = subn;
+    }
+  } else {
+    for (int64_t n = 0;; ++n) {
+      // the row of step n + 1 is requested before row n is saved (clamped: always a valid row, so the load is unconditional);
+      // it is first needed by the register rotation after the compute phase
+      next_index();
+      const int64_t k1 = (kn < klast) ? kn : klast;
+      load_action(k1, a1);
+      save_row(n, sv);
+      if (n == N) break;
+      advance(a0, a1, k, k1);
 #pragma unroll
-    for (int v = 0; v < V; ++v)
+      for (int q = 0; q < A; ++q)
 #pragma unroll
-      for (int q = 0; q < A; ++q) a_cur[v][q] = a_nxt[v][q];
-    k = kn;
-    sub = subn;
+        for (int v = 0; v < V; ++v) a0[q][v] = a1[q][v];
+      k = kn;
+      sub = subn;
+    }
   }
+  publish_last(sv);
 }
 
 // ---- probes for the in-kernel math (tests) ---------------------------------------------------

@@ -9,6 +9,9 @@
 namespace excenv {
 
 void set_error(const char* fmt, ...);
+// Set by EXCENV_LAUNCH_DYN when raising a kernel's dynamic-LDS limit failed (the launch is then skipped and
+// check_launch reports the stored message instead of a generic launch error). Per thread, like the error string.
+static thread_local bool g_attr_failed = false;
 
 struct StepCall {
   int vec_pref;  // 0 auto, else forced envs per lane
@@ -45,8 +48,17 @@ struct SimCall {
   int vec_pref;  // 0 auto, else forced envs-per-lane (1, 2, 4)
   int lds_pad;   // dynamic LDS bytes per workgroup (occupancy shaping experiments; 0 = none)
   int em_mode;   // env-major buffers: 0 = fused LDS time-tile kernel when eligible, 1 = never (generic strides / workspace)
+  const excenv_traj_gym_t* gym;  // optional reward / terminated / truncated trajectories
   hipStream_t stream;
 };
+
+// The fused env-major kernel applies when both layouts are env-major, substeps == 1, the caller did not opt out, no gym
+// trajectories are requested and the time tile fits LDS. Decided once per call (excenv_api.hip) and handed to launch_sim.
+static inline bool em_fused_eligible(int em_mode, int action_layout, int traj_layout, int32_t substeps, bool with_gym,
+                                     int A, int OW, int S, bool with_states, size_t elem) {
+  return em_mode != 1 && action_layout == EXCENV_LAYOUT_ENV_MAJOR && traj_layout == EXCENV_LAYOUT_ENV_MAJOR &&
+         substeps == 1 && !with_gym && em_lds_elems<float>(A, OW, S, with_states) * elem <= 150 * 1024;
+}
 
 struct EnvVTable {
   int S, A, O, P;
@@ -85,9 +97,18 @@ static bool fill_props(KProps<T, M>& kp, const excenv_props_t* p) {
 // Launch with dynamic LDS; above the default 64 KiB limit the kernel's attribute is raised first (gfx950: 160 KiB per CU).
 #define EXCENV_LAUNCH_DYN(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS)                                                         \
   do {                                                                                                                   \
-    if ((LDS) > 64 * 1024)                                                                                               \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
-    hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS);                                                          \
+    bool excenv_attr_ok = true;                                                                                          \
+    if ((LDS) > 64 * 1024) {                                                                                             \
+      const hipError_t excenv_e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),                            \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));            \
+      if (excenv_e != hipSuccess) {                                                                                      \
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", (int)(LDS),                         \
+                  hipGetErrorString(excenv_e));                                                                          \
+        g_attr_failed = true;                                                                                            \
+        excenv_attr_ok = false;                                                                                          \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    if (excenv_attr_ok) hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS);                                      \
   } while (0)
 
 // Dynamic LDS for the saturated model's tables: staged when they fit LDS (<= 150 KiB, leaving room for one workgroup).
@@ -105,6 +126,11 @@ template <typename T, class M> static size_t lut_lds_bytes(KProps<T, M>& kp, siz
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static inline int check_launch(const char* what) {
+  if (g_attr_failed) {  // message already set by EXCENV_LAUNCH_DYN
+    g_attr_failed = false;
+    (void)hipGetLastError();
+    return EXCENV_EHIP;
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
@@ -130,6 +156,15 @@ template <class M> static int pmsm_coef(const excenv_props_t* p, double env_tau,
     *coef = (d.value + 0.5) * env_tau;
   }
   return EXCENV_OK;
+}
+
+// Envs per lane for a batch: the widest 16-byte form that still leaves at least one wave per SIMD on the chip
+// (256 CUs x 4 SIMDs = 1024 waves of 64 lanes); small batches run one env per lane so that the per-step dependent chain
+// of a wave is as short as possible (batch sweep).
+static inline int auto_envs_per_lane(int64_t B, int vmax) {
+  int v = vmax;
+  while (v > 1 && (B / v) < (int64_t)1024 * 64) v >>= 1;
+  return v;
 }
 
 template <class M, typename T> static int launch_step(const StepCall& sc) {
@@ -163,8 +198,9 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
   }
   if (sc.B == 0) return EXCENV_OK;
   constexpr int VMAX = 16 / (int)sizeof(T);
+  const bool general = batched || ka.n_control > 0 || ka.reward != nullptr;
   int V = 1;
-  if (!batched && ka.n_control == 0 && ka.reward == nullptr) {
+  if (!general) {
     bool ok = true;
     for (int j = 0; j < M::S; ++j) ok &= aligned16(ka.state_in[j]) && aligned16(ka.state_out[j]);
     int want = sc.vec_pref > 0 ? sc.vec_pref : 1;  // measured: one env per lane is fastest on this path
@@ -175,12 +211,12 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
   const size_t step_lds = lut_lds_bytes<T, M>(ka.kp, 0);
-#define EXCENV_STEP_LAUNCH(SOLV, BAT, VV) EXCENV_LAUNCH_DYN((step_kernel<M, T, SOLV, BAT, VV>), grid, block, step_lds, sc.stream, ka)
-#define EXCENV_STEP_CASE(SOLV)                                             \
-  case SOLV:                                                               \
-    if (batched) EXCENV_STEP_LAUNCH(SOLV, true, 1);                        \
-    else if (V == 2) EXCENV_STEP_LAUNCH(SOLV, false, 2);                   \
-    else if (V == 1) EXCENV_STEP_LAUNCH(SOLV, false, 1);                   \
+#define EXCENV_STEP_LAUNCH(SOLV, GEN, VV) EXCENV_LAUNCH_DYN((step_kernel<M, T, SOLV, GEN, VV>), grid, block, step_lds, sc.stream, ka)
+#define EXCENV_STEP_CASE(SOLV)                                                 \
+  case SOLV:                                                                   \
+    if (general) EXCENV_STEP_LAUNCH(SOLV, true, 1);                            \
+    else if (V == 2) EXCENV_STEP_LAUNCH(SOLV, false, 2);                       \
+    else if (V == 1) EXCENV_STEP_LAUNCH(SOLV, false, 1);                       \
     else { if constexpr (sizeof(T) == 4) EXCENV_STEP_LAUNCH(SOLV, false, 4); } \
     break;
   switch (sc.solver) {
@@ -195,13 +231,13 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
 }
 
 template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(const SimCall& sc_in, const SimArgs<T, M>& ka_in,
-                                                                                 bool batched, int V) {
+                                                                                 bool general, int V) {
   SimArgs<T, M> ka = ka_in;
   SimCall sc = sc_in;
   sc.lds_pad = (int)lut_lds_bytes<T, M>(ka.kp, (size_t)sc_in.lds_pad);
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
-  if (batched) {
+  if (general) {
     EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, true, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
     return;
   }
@@ -228,7 +264,9 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   ka.n_control = sc.control ? sc.control->n_control : 0;
   const int64_t N = sc.K * sc.substeps;
   const int64_t OW = M::O + ka.n_control;
-  bool vec_ok = !batched;
+  const bool with_gym = sc.gym != nullptr;
+  const bool general = batched || ka.n_control > 0 || with_gym;
+  bool vec_ok = !general;
   for (int j = 0; j < M::S; ++j) {
     if (!sc.state_in[j] || !sc.last_state[j]) { set_error("excenv_sim_ahead: state pointer %d is NULL", j); return EXCENV_ENULL; }
     ka.state_in[j] = (const T*)sc.state_in[j];
@@ -258,10 +296,27 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     set_error("excenv_sim_ahead: the tiled layout needs batch_size %% %lld == 0", (long long)TILE);
     return EXCENV_EINVAL;
   }
+  if (with_gym) {
+    if (!sc.gym->reward || !sc.gym->terminated || !sc.gym->truncated) {
+      set_error("excenv_sim_ahead: gym trajectories need all of reward, terminated and truncated");
+      return EXCENV_ENULL;
+    }
+    if (tiled_t) { set_error("excenv_sim_ahead: gym trajectories are not available in the tiled layout"); return EXCENV_EUNSUPPORTED; }
+    const int64_t TW = (M::IS_PMSM || M::ID == EXCENV_FLUID_TANK) ? 1 : OW;
+    ka.reward = (T*)sc.gym->reward;
+    ka.terminated = sc.gym->terminated;
+    ka.truncated = sc.gym->truncated;
+    if (sc.traj_layout == EXCENV_LAYOUT_ENV_MAJOR) {
+      ka.g_sb = N; ka.g_sk = 1;
+      ka.t_sb = (N + 1) * TW; ka.t_sk = TW; ka.t_sc = 1;
+    } else {
+      ka.g_sb = 1; ka.g_sk = sc.B;
+      ka.t_sb = 1; ka.t_sk = TW * sc.B; ka.t_sc = sc.B;
+    }
+  }
   for (int j = 0; j < ka.n_control; ++j) {
     ka.control_idx[j] = sc.control->control_idx[j];
     ka.reference[j] = (const T*)sc.control->reference[j];
-    vec_ok &= aligned16(ka.reference[j]);
   }
   ka.dt = (T)sc.obs_stepsize;
   ka.env_tau = (T)sc.env_tau;
@@ -276,45 +331,42 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     }
   }
 
-  if (sc.action_layout == EXCENV_LAYOUT_ENV_MAJOR && sc.traj_layout == EXCENV_LAYOUT_ENV_MAJOR && sc.substeps == 1 &&
-      sc.em_mode != 1) {
-    // fused env-major kernel: one wave per 64 envs, TK steps staged in LDS, per-env contiguous runs written out
+  if (sc.em_mode == 2) {  // decided by the caller (em_fused_eligible): fused env-major kernel, one wave per 64 envs,
+                          // TK steps staged in LDS, per-env contiguous runs written out
     const size_t lds = em_lds_elems<T>(M::A, (int)OW, M::S, sc.state_traj != nullptr) * sizeof(T);
-    if (lds <= 150 * 1024) {
-      const dim3 grid((unsigned)((sc.B + EM_LANES - 1) / EM_LANES)), block(EM_LANES);
+    const dim3 grid((unsigned)((sc.B + EM_LANES - 1) / EM_LANES)), block(EM_LANES);
 #define EXCENV_EM_CASE(SOLV)                                                                                             \
   case SOLV:                                                                                                             \
     if (sc.semantics == EXCENV_SEM_AHEAD) {                                                                              \
-      if (batched) EXCENV_LAUNCH_DYN((sim_ahead_em_kernel<M, T, SOLV, true, true>), grid, block, lds, sc.stream, ka);   \
+      if (general) EXCENV_LAUNCH_DYN((sim_ahead_em_kernel<M, T, SOLV, true, true>), grid, block, lds, sc.stream, ka);   \
       else EXCENV_LAUNCH_DYN((sim_ahead_em_kernel<M, T, SOLV, true, false>), grid, block, lds, sc.stream, ka);          \
     } else {                                                                                                             \
-      if (batched) EXCENV_LAUNCH_DYN((sim_ahead_em_kernel<M, T, SOLV, false, true>), grid, block, lds, sc.stream, ka);  \
+      if (general) EXCENV_LAUNCH_DYN((sim_ahead_em_kernel<M, T, SOLV, false, true>), grid, block, lds, sc.stream, ka);  \
       else EXCENV_LAUNCH_DYN((sim_ahead_em_kernel<M, T, SOLV, false, false>), grid, block, lds, sc.stream, ka);         \
     }                                                                                                                    \
     break;
-      switch (sc.solver) {
-        EXCENV_EM_CASE(EXCENV_EULER)
-        EXCENV_EM_CASE(EXCENV_RK4)
-        EXCENV_EM_CASE(EXCENV_TSIT5)
-        default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
-      }
-#undef EXCENV_EM_CASE
-      return check_launch("excenv_sim_ahead (env-major fused)");
+    switch (sc.solver) {
+      EXCENV_EM_CASE(EXCENV_EULER)
+      EXCENV_EM_CASE(EXCENV_RK4)
+      EXCENV_EM_CASE(EXCENV_TSIT5)
+      default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
     }
+#undef EXCENV_EM_CASE
+    return check_launch("excenv_sim_ahead (env-major fused)");
   }
   vec_ok &= (sc.action_layout != EXCENV_LAYOUT_ENV_MAJOR) && (sc.traj_layout != EXCENV_LAYOUT_ENV_MAJOR);
   vec_ok &= aligned16(ka.actions) && aligned16(ka.obs);
   constexpr int VMAX = 16 / (int)sizeof(T);
   int V = 1;
   if (vec_ok) {
-    int want = sc.vec_pref > 0 ? sc.vec_pref : VMAX;
+    int want = sc.vec_pref > 0 ? sc.vec_pref : auto_envs_per_lane(sc.B, VMAX);
     if (want > VMAX) want = VMAX;
     while (want > 1 && (sc.B % want) != 0) want >>= 1;
     V = want;
   }
   if (tiled_a || tiled_t) {  // a workgroup must not straddle tiles
     constexpr int VT = (int)(TILE / BLOCK);
-    if (VT > VMAX || batched || !vec_ok) {
+    if (VT > VMAX || general || !vec_ok) {
       if (TILE % BLOCK != 0) { set_error("tiled layout: TILE %% BLOCK != 0"); return EXCENV_EINVAL; }
       V = 1;
     } else {
@@ -331,14 +383,14 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     ka.o_wg = wg_off(sc.traj_layout, ka.o_sb, (N + 1) * OW * TILE);
     ka.s_wg = wg_off(sc.traj_layout, ka.s_sb, (N + 1) * TILE);
     if (ka.a_wg < 0 || ka.o_wg < 0 || ka.s_wg < 0) {
-      set_error("excenv_sim_ahead: tiled layout needs unbatched properties, 16-byte aligned buffers and the %d-byte dtype", 4);
+      set_error("excenv_sim_ahead: tiled layout needs unbatched properties, no control columns, 16-byte aligned buffers and the %d-byte dtype", 4);
       return EXCENV_EUNSUPPORTED;
     }
   }
 #define EXCENV_SIM_CASE(SOLV)                                                         \
   case SOLV:                                                                          \
-    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(sc, ka, batched, V);  \
-    else launch_sim_v<M, T, SOLV, false>(sc, ka, batched, V);                         \
+    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(sc, ka, general, V);  \
+    else launch_sim_v<M, T, SOLV, false>(sc, ka, general, V);                         \
     break;
   switch (sc.solver) {
     EXCENV_SIM_CASE(EXCENV_EULER)

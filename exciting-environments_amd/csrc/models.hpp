@@ -381,18 +381,24 @@ __device__ __forceinline__ void pick_field(const T (&st)[M::S], const Ctx<T, M>&
   }
 }
 
-// e.g. pendulum_env.py:297-309, mass_spring_damper_env.py:296-302, pmsm_env.py:985-1037
+// e.g. pendulum_env.py:297-309, mass_spring_damper_env.py:296-302, pmsm_env.py:985-1037. The control loop is unrolled
+// over EXCENV_MAX_CONTROL with a uniform guard so that `ref` (registers) is only indexed statically.
 template <class M, typename T>
-__device__ __forceinline__ T env_reward(const T (&st)[M::S], const Ctx<T, M>& c, int n_control, const int* idx, const T* ref) {
+__device__ __forceinline__ T env_reward(const T (&st)[M::S], const Ctx<T, M>& c, int n_control, const int* idx,
+                                        const T (&ref)[EXCENV_MAX_CONTROL]) {
   T reward = T(0);
   if constexpr (M::IS_PMSM) {
     // control_state membership: "i_d" (3), "i_q" (4), "torque" (5)
     T r_id = T(0), r_iq = T(0), r_tq = T(0);
     bool has_id = false, has_iq = false, has_tq = false;
-    for (int j = 0; j < n_control; ++j) {
-      if (idx[j] == 3) { has_id = true; r_id = ref[j]; }
-      if (idx[j] == 4) { has_iq = true; r_iq = ref[j]; }
-      if (idx[j] == 5) { has_tq = true; r_tq = ref[j]; }
+#pragma unroll
+    for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+      if (j < n_control) {
+        const int f = idx[j];
+        if (f == 3) { has_id = true; r_id = ref[j]; }
+        if (f == 4) { has_iq = true; r_iq = ref[j]; }
+        if (f == 5) { has_tq = true; r_tq = ref[j]; }
+      }
     }
     const T i_d = normalize(st[3], c.smin[3], c.smax[3]);
     const T i_q = normalize(st[4], c.smin[4], c.smax[4]);
@@ -417,23 +423,26 @@ __device__ __forceinline__ T env_reward(const T (&st)[M::S], const Ctx<T, M>& c,
       reward = reward + rew * T(1 - 0.85);
     }
   } else {
-    for (int j = 0; j < n_control; ++j) {
-      const int f = idx[j];
-      T x, lo, hi;
-      pick_field<M, T>(st, c, f, x, lo, hi);
-      const T r = ref[j];
-      bool ang = false;
 #pragma unroll
-      for (int q = 0; q < M::S; ++q) ang = ang || (is_angle_field<M>(q) && f == q);
-      if (ang) {
-        T sx, cx, sr, cr;
-        sincos_t(x, sx, cx);
-        sincos_t(r, sr, cr);
-        const T ds = sx - sr, dc = cx - cr;
-        reward = reward + -(ds * ds + dc * dc);
-      } else {
-        const T d = normalize(x, lo, hi) - normalize(r, lo, hi);
-        reward = reward + -(d * d);
+    for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+      if (j < n_control) {
+        const int f = idx[j];
+        T x, lo, hi;
+        pick_field<M, T>(st, c, f, x, lo, hi);
+        const T r = ref[j];
+        bool ang = false;
+#pragma unroll
+        for (int q = 0; q < M::S; ++q) ang = ang || (is_angle_field<M>(q) && f == q);
+        if (ang) {
+          T sx, cx, sr, cr;
+          sincos_t(x, sx, cx);
+          sincos_t(r, sr, cr);
+          const T ds = sx - sr, dc = cx - cr;
+          reward = reward + -(ds * ds + dc * dc);
+        } else {
+          const T d = normalize(x, lo, hi) - normalize(r, lo, hi);
+          reward = reward + -(d * d);
+        }
       }
     }
   }

@@ -17,6 +17,7 @@ LAYOUT_ENV_MAJOR, LAYOUT_LANE_MAJOR, LAYOUT_TILED = 0, 1, 2
 TILE = 1024  # EXCENV_TILE
 SEM_STEP, SEM_AHEAD = 0, 1
 F32, F64 = 0, 1
+ABI_VERSION = 3
 
 _LIB_PATH = os.environ.get(  # EXCENV_HIP_LIB: A/B-test another build of the same library (tuning experiments)
     "EXCENV_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libexcenv_hip.so"))
@@ -40,6 +41,19 @@ class Props(ctypes.Structure):
         ("action_max", Param * MAX_ACTION),
         ("pmsm_lut", ctypes.POINTER(PmsmLut)),
     ]
+
+
+class LaunchOpts(ctypes.Structure):
+    """excenv_launch_opts_t: per-call launch shaping (None / NULL = defaults)."""
+
+    _fields_ = [("envs_per_lane", ctypes.c_int32), ("env_major_mode", ctypes.c_int32), ("lds_pad_bytes", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class TrajGym(ctypes.Structure):
+    """excenv_traj_gym_t: optional reward / terminated / truncated trajectories of excenv_sim_ahead."""
+
+    _fields_ = [("reward", ctypes.c_void_p), ("terminated", ctypes.c_void_p), ("truncated", ctypes.c_void_p)]
 
 
 class Control(ctypes.Structure):
@@ -75,9 +89,9 @@ def lib():
         l.excenv_sim_ahead_workspace_bytes.restype = ctypes.c_int64
         l.excenv_truncated_width.restype = ctypes.c_int32
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
-                   "excenv_probe_math", "excenv_set_tuning"):
+                   "excenv_probe_math"):
             getattr(l, fn).restype = ctypes.c_int
-        if l.excenv_abi_version() != 2:
+        if l.excenv_abi_version() != ABI_VERSION:
             raise ImportError("libexcenv_hip.so: ABI version mismatch")
         _lib = l
     return _lib
@@ -146,8 +160,12 @@ def sim_ahead_bytes(env_id: int, dtype: torch.dtype, with_state_traj: bool = Tru
     return int(lib().excenv_sim_ahead_bytes(env_id, dtype_id(dtype), int(with_state_traj)))
 
 
-def set_tuning(key: int, value: int) -> int:
-    return int(lib().excenv_set_tuning(key, value))
+def launch_opts(envs_per_lane: int = 0, env_major_mode: int = 0, lds_pad_bytes: int = 0) -> LaunchOpts:
+    return LaunchOpts(int(envs_per_lane), int(env_major_mode), int(lds_pad_bytes), 0)
+
+
+def _opts_ref(opts: Optional[LaunchOpts]):
+    return ctypes.byref(opts) if opts is not None else None
 
 
 def make_control(control_idx: Sequence[int], refs: Sequence[torch.Tensor]) -> Optional[Control]:
@@ -163,7 +181,7 @@ def make_control(control_idx: Sequence[int], refs: Sequence[torch.Tensor]) -> Op
 
 def step(env_id, solver_id, dtype, B, props: Props, control: Optional[Control], tau: float,
          state_in: Sequence[torch.Tensor], action: torch.Tensor, state_out: Sequence[torch.Tensor],
-         obs: torch.Tensor):
+         obs: torch.Tensor, opts: Optional[LaunchOpts] = None):
     _require_device(action, "vmap_step")
     with _on_device(action.device):
         stream = _raw_stream(action.device)
@@ -171,7 +189,7 @@ def step(env_id, solver_id, dtype, B, props: Props, control: Optional[Control], 
             ctypes.c_int(env_id), ctypes.c_int(solver_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B),
             ctypes.byref(props), ctypes.byref(control) if control is not None else None, ctypes.c_double(tau),
             _ptrs(state_in), ctypes.c_void_p(action.data_ptr()), _ptrs(state_out), ctypes.c_void_p(obs.data_ptr()),
-            ctypes.c_void_p(stream),
+            _opts_ref(opts), ctypes.c_void_p(stream),
         )
     _check(rc, "excenv_step")
 
@@ -182,7 +200,8 @@ def truncated_width(env_id: int, n_control: int) -> int:
 
 def gym_step(env_id, solver_id, dtype, B, props: Props, control: Optional[Control], tau: float,
              state_in: Sequence[torch.Tensor], action: torch.Tensor, state_out: Sequence[torch.Tensor],
-             obs: torch.Tensor, reward: torch.Tensor, terminated: torch.Tensor, truncated: torch.Tensor):
+             obs: torch.Tensor, reward: torch.Tensor, terminated: torch.Tensor, truncated: torch.Tensor,
+             opts: Optional[LaunchOpts] = None):
     _require_device(action, "gym_step")
     with _on_device(action.device):
         stream = _raw_stream(action.device)
@@ -191,7 +210,7 @@ def gym_step(env_id, solver_id, dtype, B, props: Props, control: Optional[Contro
             ctypes.byref(props), ctypes.byref(control) if control is not None else None, ctypes.c_double(tau),
             _ptrs(state_in), ctypes.c_void_p(action.data_ptr()), _ptrs(state_out), ctypes.c_void_p(obs.data_ptr()),
             ctypes.c_void_p(reward.data_ptr()), ctypes.c_void_p(terminated.data_ptr()),
-            ctypes.c_void_p(truncated.data_ptr()), ctypes.c_void_p(stream),
+            ctypes.c_void_p(truncated.data_ptr()), _opts_ref(opts), ctypes.c_void_p(stream),
         )
     _check(rc, "excenv_gym_step")
 
@@ -200,8 +219,12 @@ def sim_ahead(env_id, solver_id, dtype, B, K, substeps, props: Props, control: O
               obs_stepsize: float, env_tau: float, state_in: Sequence[torch.Tensor], actions: torch.Tensor,
               action_layout: int, obs_traj: torch.Tensor, state_traj: Optional[Sequence[torch.Tensor]],
               traj_layout: int, last_state: Sequence[torch.Tensor], semantics: int,
-              workspace: Optional[torch.Tensor] = None):
+              workspace: Optional[torch.Tensor] = None, opts: Optional[LaunchOpts] = None, gym=None):
+    """gym: None or (reward, terminated, truncated) device tensors in the trajectory layout (excenv_traj_gym_t)."""
     _require_device(obs_traj, "vmap_sim_ahead")
+    g = None
+    if gym is not None:
+        g = TrajGym(gym[0].data_ptr(), gym[1].data_ptr(), gym[2].data_ptr())
     with _on_device(obs_traj.device):
         stream = _raw_stream(obs_traj.device)
         rc = lib().excenv_sim_ahead_ws(
@@ -211,9 +234,10 @@ def sim_ahead(env_id, solver_id, dtype, B, K, substeps, props: Props, control: O
             ctypes.c_double(env_tau), _ptrs(state_in), ctypes.c_void_p(actions.data_ptr() if K > 0 else None),
             ctypes.c_int(action_layout), ctypes.c_void_p(obs_traj.data_ptr()),
             _ptrs(state_traj) if state_traj is not None else None, ctypes.c_int(traj_layout), _ptrs(last_state),
-            ctypes.c_int(semantics), ctypes.c_void_p(workspace.data_ptr() if workspace is not None else None),
+            ctypes.c_int(semantics), ctypes.byref(g) if g is not None else None,
+            ctypes.c_void_p(workspace.data_ptr() if workspace is not None else None),
             ctypes.c_int64(workspace.numel() * workspace.element_size() if workspace is not None else 0),
-            ctypes.c_void_p(stream),
+            _opts_ref(opts), ctypes.c_void_p(stream),
         )
     _check(rc, "excenv_sim_ahead")
 

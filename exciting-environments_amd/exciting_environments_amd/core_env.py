@@ -103,6 +103,8 @@ class CoreEnvironment(ABC):
         # False: vmap_sim_ahead skips the physical-state trajectories (`states` is None; 40 instead of 68 bytes per
         # PMSM env-step). The reference always returns them, so the default is True.
         self.store_state_trajectory = True
+        # per-call launch options (excenv_launch_opts_t); None = library defaults. Tuning experiments only.
+        self.launch_opts = None
         self._packed_props = None
         self._flag_cache = {}
         self._obs_dim_cache = None
@@ -352,7 +354,7 @@ class CoreEnvironment(ABC):
         st_out = [buf[j * (B + pad): j * (B + pad) + B] for j in range(S)]
         obs = buf[S * (B + pad):].view(B, O)
         _native.step(self.ENV_ID, self._solver.id, self.dtype, B, props, control, float(self.tau), st_in, act,
-                     st_out, obs)
+                     st_out, obs, self.launch_opts)
         return obs, st_out
 
     def _obs_dim(self):
@@ -550,10 +552,11 @@ class CoreEnvironment(ABC):
                                                        a_layout, t_layout, want_states)
             if nbytes > 0:
                 workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        if _native.LAYOUT_ENV_MAJOR in (a_layout, t_layout):
-            _native.set_tuning(2, 0 if self.env_major_fused else 1)
+        opts = self.launch_opts
+        if _native.LAYOUT_ENV_MAJOR in (a_layout, t_layout) and not self.env_major_fused:
+            opts = _native.launch_opts(opts.envs_per_lane if opts else 0, 1, opts.lds_pad_bytes if opts else 0)
         _native.sim_ahead(self.ENV_ID, self._solver.id, self.dtype, B, K, sub, props, control, float(obs_stepsize),
-                          float(self.tau), st_in, actions, a_layout, obs_buf, st_buf, t_layout, last, sem, workspace)
+                          float(self.tau), st_in, actions, a_layout, obs_buf, st_buf, t_layout, last, sem, workspace, opts)
         return observations, st_views, last, N
 
     def _traj_state(self, init_state, st_views, lead_shape, N):

@@ -60,7 +60,10 @@ class ObservationGatherer:
     """All-gather of per-rank observation shards [B_r, ...] into the global [B, ...] array on every rank.
 
     ``start`` enqueues the collective on a side stream (after the producer stream's work) and returns at once;
-    ``wait`` makes the current stream wait for it. With the "nccl" backend this is one ncclAllGather per call.
+    ``wait`` makes the current stream of the same device wait for it. The collective is chosen once, up front:
+    even shards use ``all_gather_into_tensor`` (one ncclAllGather with the "nccl" backend = RCCL; gloo implements it too),
+    ragged shards use the list form on shards padded to the largest one. Errors of the collective propagate — there
+    is no fallback from one form to the other.
     """
 
     def __init__(self, global_batch: int, group: Optional[dist.ProcessGroup] = None):
@@ -70,21 +73,20 @@ class ObservationGatherer:
         self.global_batch = global_batch
         self.sizes = shard_sizes(global_batch, self.world)
         self.even = len(set(self.sizes)) == 1
+        self.collective = "all_gather_into_tensor" if self.even else "all_gather(list, padded)"
         self._stream = None
         self._event = None
+        self._device = None
 
     def _side_stream(self, device):
-        if self._stream is None:
+        if self._stream is None or self._stream.device != device:
             self._stream = torch.cuda.Stream(device=device)
         return self._stream
 
     def _gather(self, local: torch.Tensor, out: torch.Tensor):
         if self.even:
-            try:
-                dist.all_gather_into_tensor(out, local, group=self.group)
-                return
-            except (RuntimeError, NotImplementedError):
-                pass
+            dist.all_gather_into_tensor(out, local, group=self.group)
+            return
         pad = max(self.sizes)
         buf = local
         if local.shape[0] != pad:
@@ -103,6 +105,7 @@ class ObservationGatherer:
         if out is None:
             out = local.new_empty((self.global_batch,) + tuple(local.shape[1:]))
         if local.is_cuda:
+            self._device = local.device
             side = self._side_stream(local.device)
             side.wait_stream(torch.cuda.current_stream(local.device))
             with torch.cuda.stream(side):
@@ -116,5 +119,5 @@ class ObservationGatherer:
 
     def wait(self):
         if self._event is not None:
-            torch.cuda.current_stream().wait_event(self._event)
+            torch.cuda.current_stream(self._device).wait_event(self._event)
             self._event = None

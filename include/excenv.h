@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXCENV_ABI_VERSION 2
+#define EXCENV_ABI_VERSION 3
 
 /* Environment ids. Field orders follow the reference dataclasses. */
 typedef enum {
@@ -115,6 +115,34 @@ typedef struct {
   const void* reference[EXCENV_MAX_CONTROL];
 } excenv_control_t;
 
+/* Per-call launch options (no reference counterpart; NULL = all defaults). Everything that shapes a launch travels
+ * with the call: the library keeps no mutable state besides the per-thread error string.
+ *   envs_per_lane  : lane-major / tiled trajectories and the step path: 0 = auto (16-byte accesses when the batch is large
+ *                    enough to fill the chip that way, else one env per lane), 1 / 2 / 4 = forced
+ *   env_major_mode : env-major (row-major) buffers — 0: fused LDS time-tile kernel when both layouts are env-major,
+ *                    substeps == 1 and the tile fits LDS; 1: never (workspace + transposes, or generic strides)
+ *   lds_pad_bytes  : extra dynamic LDS per sim_ahead workgroup (caps resident workgroups per CU; occupancy experiments)
+ *   reserved       : must be 0 */
+typedef struct {
+  int32_t envs_per_lane;
+  int32_t env_major_mode;
+  int32_t lds_pad_bytes;
+  int32_t reserved;
+} excenv_launch_opts_t;
+
+/* Optional reward / terminated / truncated trajectories of excenv_sim_ahead — what
+ * CoreEnvironment.vmap_generate_rew_trunc_term_ahead (core_env.py:490-531, 618-647) computes from the returned states,
+ * produced by the same launch from the registers that hold each saved state. All three pointers or NULL struct.
+ *   reward     : N rows (saved rows 1..N) of one value per env, working dtype
+ *   terminated : N rows of one byte (0/1) per env
+ *   truncated  : N+1 rows (saved rows 0..N) of excenv_truncated_width() bytes per env
+ * in the trajectory layout of the call: lane-major [row][flag][B] / env-major [B][row][flag] (tiled: unsupported). */
+typedef struct {
+  void* reward;
+  uint8_t* terminated;
+  uint8_t* truncated;
+} excenv_traj_gym_t;
+
 /* ---- introspection -------------------------------------------------------------------- */
 int excenv_abi_version(void);
 const char* excenv_last_error(void);
@@ -135,7 +163,7 @@ int64_t excenv_sim_ahead_bytes(int env, int dtype, int with_state_traj);
 int excenv_step(int env, int solver, int dtype, int64_t B,
                 const excenv_props_t* props, const excenv_control_t* control, double tau,
                 const void* const* state_in, const void* action,
-                void* const* state_out, void* obs, void* stream);
+                void* const* state_out, void* obs, const excenv_launch_opts_t* opts, void* stream);
 
 /* ---- replaces GymWrapper.gym_step (gym_wrapper.py:88-130): vmap_step fused with the environment's
  * generate_reward / generate_terminated / generate_truncated (e.g. pendulum_env.py:297-309,381-390,
@@ -150,7 +178,7 @@ int excenv_gym_step(int env, int solver, int dtype, int64_t B,
                     const excenv_props_t* props, const excenv_control_t* control, double tau,
                     const void* const* state_in, const void* action,
                     void* const* state_out, void* obs, void* reward, uint8_t* terminated, uint8_t* truncated,
-                    void* stream);
+                    const excenv_launch_opts_t* opts, void* stream);
 
 /* ---- replaces CoreEnvironment.vmap_sim_ahead (core_env.py:571-616) --------------------
  * and PMSM.sim_ahead (pmsm_env.py:746-801). One persistent launch runs all N = K*substeps
@@ -167,7 +195,8 @@ int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
                      const excenv_props_t* props, const excenv_control_t* control, double obs_stepsize,
                      double env_tau, const void* const* state_in, const void* actions, int action_layout,
                      void* obs_traj, void* const* state_traj, int traj_layout,
-                     void* const* last_state, int semantics, void* stream);
+                     void* const* last_state, int semantics, const excenv_traj_gym_t* gym,
+                     const excenv_launch_opts_t* opts, void* stream);
 
 /* Same as excenv_sim_ahead, with a caller-provided device workspace. When a layout is EXCENV_LAYOUT_ENV_MAJOR
  * (the reference's row-major arrays) and `workspace_bytes >= excenv_sim_ahead_workspace_bytes(...)`, the library
@@ -180,18 +209,10 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
                         const excenv_props_t* props, const excenv_control_t* control, double obs_stepsize,
                         double env_tau, const void* const* state_in, const void* actions, int action_layout,
                         void* obs_traj, void* const* state_traj, int traj_layout, void* const* last_state,
-                        int semantics, void* workspace, int64_t workspace_bytes, void* stream);
+                        int semantics, const excenv_traj_gym_t* gym, void* workspace, int64_t workspace_bytes,
+                        const excenv_launch_opts_t* opts, void* stream);
 /* out[n][m] = in[m][n] for a row-major M x N matrix of the given dtype (the conversion kernel used above). */
 int excenv_transpose(int dtype, int64_t M, int64_t N, const void* in, void* out, void* stream);
-
-/* ---- tuning (no reference counterpart) -------------------------------------------------------
- * key 0: environments per lane for lane-major trajectories (0 = auto, 1/2/4 = forced). Process-wide.
- * key 2: env-major (row-major) buffers — 0 (default): fused LDS time-tile kernel when both layouts are env-major,
- *        substeps == 1 and the tile fits 150 KiB of LDS; 1: never (workspace + transposes, or generic strides).
- * key 1: dynamic LDS bytes requested per sim_ahead workgroup (the kernels use no LDS; this only caps the
- *        number of resident workgroups per CU for occupancy experiments; 0 = none).
- * Returns the previous value, or EXCENV_EINVAL for an unknown key. */
-int excenv_set_tuning(int key, int value);
 
 /* ---- device-math probes (tests only): out[i] = f(in[i]) for the in-kernel fp32 routines -- */
 int excenv_probe_math(int which /*0 sin,1 cos,2 wrap_angle*/, int dtype, int64_t n,

@@ -1,0 +1,100 @@
+"""The PRODUCT (HIP kernels) under torch.distributed on the GPU box: a 1-rank RCCL ("nccl") group through
+make_sharded_env + ObservationGatherer, two gloo ranks on one GPU (even and ragged shards) against the un-sharded run, and
+`python bench.py --gpus 2` invoked directly (it must start its own ranks). The CPU-side shard/gather logic is covered by
+tests/test_distributed_cpu.py. Needs an MI355X (``-m gpu``)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _child_env(**extra):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "1"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra)
+    return env
+
+
+def test_product_env_under_one_rank_rccl_group():
+    """backend "nccl" IS RCCL on ROCm: the sharded product environment steps and its observations go through one real
+    ncclAllGather (all_gather_into_tensor) on the gatherer's side stream."""
+    import torch.distributed as dist
+    from exciting_environments_amd import EnvironmentRegistry
+    from exciting_environments_amd.distributed import ObservationGatherer, make_sharded_env
+
+    assert not dist.is_initialized()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        B, K = 4096, 16
+        env, (lo, hi) = make_sharded_env(EnvironmentRegistry.PMSM, B, dtype=torch.float32, device=dev)
+        assert (lo, hi) == (0, B)
+        _, st = env.vmap_reset()
+        st.physical_state.omega_el = torch.rand(B, device=dev) * 600
+        acts = env.new_actions_buffer(K)
+        acts.uniform_(-1, 1)
+        obs, _, last = env.vmap_sim_ahead(st, acts, env.tau, env.tau)
+        g = ObservationGatherer(B)
+        assert g.collective == "all_gather_into_tensor"
+        full = g.start(obs[:, -1, :])
+        g.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(full, obs[:, -1, :]) and bool(torch.isfinite(full).all())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [4096, 4099])  # even shards (tensor all-gather) and ragged shards (padded list form)
+def test_two_gloo_ranks_step_product_shards_equal_unsharded_run(B, tmp_path):
+    out = tmp_path / "result.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_worker.py"), str(out), str(B)]
+    p = subprocess.run(cmd, env=_child_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(out.read_text())
+    assert r["world"] == 2 and r["gathered_equals_unsharded"] and r["finite"]
+    assert r["collective"] == ("all_gather_into_tensor" if B % 2 == 0 else "all_gather(list, padded)")
+    assert r["library"].endswith("libexcenv_hip.so")
+
+
+def test_bench_gpus_2_invoked_directly_starts_its_own_ranks():
+    """The driver runs `python bench.py --gpus N` with no launcher: the process must start N ranks itself (before touching
+    the GPU), print ONE JSON line and report how many ranks the backend saw."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "65536", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline"],
+                       env=_child_env(EXCENV_BENCH_ONE_GPU="1", EXCENV_BENCH_BACKEND="gloo"), capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["config"]["global_batch"] == 2 * 65536 and d["config"]["gathered_slice_matches_local"] is True
+    assert d["config"]["outputs_finite"] and d["value"] > 0 and d["scaling"] == "weak"
+    assert "cpu_baseline" not in d
+
+
+def test_bench_refuses_world_size_mismatch():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=_child_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "does not match --gpus" in (p.stderr + p.stdout)

@@ -157,3 +157,72 @@ def test_msd_tsit5_fp64_batch_2pow20_config_c4():
     exact = np.stack(exact, axis=1)
     got = np.stack([states.physical_state.deflection[:T].cpu().numpy(), states.physical_state.velocity[:T].cpu().numpy()], axis=-1)
     assert np.abs(got - exact).max() < 1e-11
+
+
+# ---------------------------------------------------------------------------------------- full-length runs
+def _full_length_run(env_name, solver, dtype, log2_batch, n_chunks, Kc, T, tau=None, semantics="ahead", seed=0):
+    """A BASELINE configuration at its full batch AND full step count, as `n_chunks` chained vmap_sim_ahead launches of
+    `Kc` steps (last_state -> init_state: the reference's continuation mechanism, core_env.py:484-486; chunking is
+    forced by its max_steps = 4096 and by HBM capacity). A tile of T oracle-checkable environments is replicated across the
+    batch; every chunk draws fresh actions. Per chunk:
+      * every tile of the observation trajectory (and of last_state) equals the first one bit for bit,
+      * last_state equals the final trajectory row and everything is finite,
+      * the first tile matches the CPU oracle started from the same chunk-initial state: bit-exact for the trig-free
+        systems over the whole chunk, <= 1e-5 (normalised units) over the first 64 rows otherwise (longer horizons amplify
+        the <= 2 ulp sin/cos differences chaotically — measured in DESIGN.md §5, not gated).
+    Returns the total number of env-steps simulated."""
+    B = 1 << log2_batch
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    spec = spec_of(env_name)
+    if tau is not None:
+        spec["tau"] = tau
+    env, _, _, _ = make_env(env_name, B, dtype, solver, spec=spec)
+    _, props_T, keepT, _ = make_env(env_name, T, dtype, solver, spec=spec, device="cpu")
+    env.sim_ahead_semantics = semantics
+    sem = oracle.SEM_AHEAD if semantics == "ahead" else oracle.SEM_STEP
+    rng = np.random.default_rng(seed)
+    st_small = random_state(env_name, T, np_dt, spec, seed=seed + 1)
+    state = _tile_state(env, st_small, B // T)
+    trig_free = env_name in ("mass_spring_damper", "fluid_tank")
+    angle_cols = {"pendulum": [0], "cartpole": [2], "acrobot": [0, 1]}.get(env_name, [])
+    steps = 0
+    for c in range(n_chunks):
+        acts_small = rng.uniform(-1, 1, (T, Kc, env.action_dim)).astype(np_dt)
+        actions = _tile_actions(env, acts_small, B // T)
+        st0 = [getattr(state.physical_state, n)[:T].cpu().numpy() for n in env.STATE_FIELDS]
+        obs, states, last = env.vmap_sim_ahead(state, actions, env.tau, env.tau)
+        assert obs.shape == (B, Kc + 1, len(env.obs_description))
+        assert _all_tiles_equal(obs, T), f"chunk {c}: observation tiles differ"
+        assert bool(torch.isfinite(obs[:, -1]).all()), f"chunk {c}: non-finite observations"
+        for n in env.STATE_FIELDS:
+            lv = getattr(last.physical_state, n)
+            assert torch.equal(lv, getattr(states.physical_state, n)[:, -1]), (c, n)
+            assert _all_tiles_equal(lv, T) and bool(torch.isfinite(lv).all()), (c, n)
+        o_ref, _, _ = oracle.sim_ahead(env_name, solver, st0, acts_small, props_T, spec["tau"], semantics=sem)
+        got = obs[:T].cpu().numpy()
+        if trig_free:
+            assert np.array_equal(got, o_ref), f"chunk {c}: not bit-exact vs the oracle"
+        else:
+            d = np.abs(got[:, :65].astype(np.float64) - o_ref[:, :65])
+            for col in angle_cols:
+                d[..., col] = np.minimum(d[..., col], np.abs(2 - d[..., col]))
+            assert d.max() <= 1e-5, f"chunk {c}: {d.max()}"
+        state = last
+        steps += B * Kc
+        del obs, states, actions
+    return steps
+
+
+def test_full_length_config_c2_pendulum_euler_fp32_10000_steps():
+    """configs[1] end to end: Pendulum Euler fp32, B = 2^20, tau = 2e-2, 10 000 steps (10 chained 1000-step launches)."""
+    assert _full_length_run("pendulum", "euler", torch.float32, 20, 10, 1000, 512, tau=2e-2, seed=210) == (1 << 20) * 10000
+
+
+def test_full_length_config_c3_pmsm_euler_fp32_10000_steps():
+    """configs[2] end to end: PMSM Euler fp32, B = 2^22, 10 000 steps (100 chained 100-step launches, full outputs)."""
+    assert _full_length_run("pmsm", "euler", torch.float32, 22, 100, 100, 1024, seed=220) == (1 << 22) * 10000
+
+
+def test_full_length_config_c4_msd_tsit5_fp64_5000_steps():
+    """configs[3] end to end: MassSpringDamper Tsit5 fp64, B = 2^20, 5 000 steps (10 chained 500-step launches)."""
+    assert _full_length_run("mass_spring_damper", "tsit5", torch.float64, 20, 10, 500, 256, seed=230) == (1 << 20) * 5000

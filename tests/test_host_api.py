@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.library_path())
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"libexcenv_hip.so does not export {sym}"
-    assert _native.lib().excenv_abi_version() == 2
+    assert _native.lib().excenv_abi_version() == 3
 
 
 def test_env_dims_and_algorithmic_bytes():
@@ -47,16 +47,22 @@ def test_abi_argument_validation_without_gpu():
     """Bad enums / NULL pointers are rejected by the C ABI before any HIP call."""
     lib = _native.lib()
     p = _native.Props()
-    rc = lib.excenv_step(99, 0, 0, ctypes.c_int64(4), ctypes.byref(p), None, ctypes.c_double(1e-4), None, None, None, None, None)
+    rc = lib.excenv_step(99, 0, 0, ctypes.c_int64(4), ctypes.byref(p), None, ctypes.c_double(1e-4), None, None, None, None, None, None)
     assert rc == -1 and b"bad env id" in lib.excenv_last_error()
-    rc = lib.excenv_step(0, 7, 0, ctypes.c_int64(4), ctypes.byref(p), None, ctypes.c_double(1e-4), None, None, None, None, None)
+    rc = lib.excenv_step(0, 7, 0, ctypes.c_int64(4), ctypes.byref(p), None, ctypes.c_double(1e-4), None, None, None, None, None, None)
     assert rc == -1 and b"bad solver id" in lib.excenv_last_error()
-    rc = lib.excenv_step(0, 0, 0, ctypes.c_int64(4), ctypes.byref(p), None, ctypes.c_double(1e-4), None, None, None, None, None)
+    rc = lib.excenv_step(0, 0, 0, ctypes.c_int64(4), ctypes.byref(p), None, ctypes.c_double(1e-4), None, None, None, None, None, None)
     assert rc == -2
     rc = lib.excenv_sim_ahead(0, 0, 0, ctypes.c_int64(4), ctypes.c_int64(-1), 1, ctypes.byref(p), None, ctypes.c_double(1e-4),
-                              ctypes.c_double(1e-4), None, None, 0, None, None, 0, None, 0, None)
+                              ctypes.c_double(1e-4), None, None, 0, None, None, 0, None, 0, None, None, None)
     assert rc == -1
-    assert lib.excenv_set_tuning(5, 1) == -1 and lib.excenv_set_tuning(1, 0) == 0
+    # per-call launch options are validated too (and there is no process-wide tuning entry point any more)
+    bad = _native.LaunchOpts(3, 0, 0, 0)
+    one = (ctypes.c_void_p * 8)(*([1] * 8))
+    rc = lib.excenv_step(0, 0, 0, ctypes.c_int64(4), ctypes.byref(p), None, ctypes.c_double(1e-4), one, ctypes.c_void_p(16),
+                         one, ctypes.c_void_p(16), ctypes.byref(bad), None)
+    assert rc == -1 and b"envs_per_lane" in lib.excenv_last_error()
+    assert not hasattr(lib, "excenv_set_tuning")
 
 
 @pytest.mark.parametrize("env_type", envs_to_test)

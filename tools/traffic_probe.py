@@ -36,7 +36,7 @@ del src, dst
 env, state, actions, B, Kc, reg, solver, dtype = bench.build_env(a, dev, 0)
 if a.vec:
     from exciting_environments_amd import _native
-    _native.set_tuning(0, a.vec)
+    env.launch_opts = _native.launch_opts(envs_per_lane=a.vec)
 for _ in range(a.launches):
     if a.path == "step":
         obs, state = env.vmap_step(state, actions[:, 0, :].contiguous())
