@@ -14,11 +14,12 @@ from .envs import Acrobot, CartPole, FluidTank, MassSpringDamper, MotorVariant, 
 from .registration import EnvironmentRegistry
 from .gym_wrapper import GymWrapper
 from .solvers import Euler, RK4, Tsit5
+from .stepper import Stepper
 from .utils import MinMaxNormalization, dump_sim_properties_to_json, load_sim_properties_from_json
 from . import random, tree, utils
 
 __all__ = [
     "CoreEnvironment", "Acrobot", "CartPole", "FluidTank", "MassSpringDamper", "Pendulum", "PMSM", "MotorVariant", "prepare_pmsm_lut",
-    "EnvironmentRegistry", "GymWrapper", "Euler", "RK4", "Tsit5", "MinMaxNormalization", "dump_sim_properties_to_json",
+    "EnvironmentRegistry", "GymWrapper", "Stepper", "Euler", "RK4", "Tsit5", "MinMaxNormalization", "dump_sim_properties_to_json",
     "load_sim_properties_from_json", "random", "tree", "utils",
 ]

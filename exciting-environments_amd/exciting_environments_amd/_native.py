@@ -91,6 +91,10 @@ def lib():
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
                    "excenv_probe_math"):
             getattr(l, fn).restype = ctypes.c_int
+        vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+        # typed prototypes: plain Python ints / floats / None / byref() pass without per-call ctypes wrapping
+        l.excenv_step.argtypes = [ci, ci, ci, cl, vp, vp, cd, vp, vp, vp, vp, vp, vp]
+        l.excenv_gym_step.argtypes = [ci, ci, ci, cl, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         if l.excenv_abi_version() != ABI_VERSION:
             raise ImportError("libexcenv_hip.so: ABI version mismatch")
         _lib = l
@@ -144,6 +148,30 @@ class _on_device:
 
 def _ptrs(tensors: Sequence[torch.Tensor]):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def ptr_array(addresses: Sequence[int]):
+    """void*[n] from raw device addresses (pre-built once per output slot on the vmap_step fast path)."""
+    return (ctypes.c_void_p * len(addresses))(*addresses)
+
+
+_get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def step_raw(env_id, solver_id, dtype_code, B, props_ref, control_ref, tau, in_ptrs, action_ptr, out_ptrs, obs_ptr, opts_ref,
+             device_index, gym=None):
+    """excenv_step / excenv_gym_step with every argument already in its C form (pointer arrays and byref()s cached by the
+    caller). `gym` = (reward_ptr, terminated_ptr, truncated_ptr) selects excenv_gym_step. The caller guarantees that
+    `device_index` is the current device."""
+    stream = _get_raw_stream(device_index) if _get_raw_stream is not None else torch.cuda.current_stream().cuda_stream
+    if gym is None:
+        rc = _lib.excenv_step(env_id, solver_id, dtype_code, B, props_ref, control_ref, tau, in_ptrs, action_ptr, out_ptrs,
+                              obs_ptr, opts_ref, stream)
+    else:
+        rc = _lib.excenv_gym_step(env_id, solver_id, dtype_code, B, props_ref, control_ref, tau, in_ptrs, action_ptr, out_ptrs,
+                                  obs_ptr, gym[0], gym[1], gym[2], opts_ref, stream)
+    if rc != 0:
+        _check(rc, "excenv_step" if gym is None else "excenv_gym_step")
 
 
 def env_dims(env_id: int):

@@ -10,10 +10,12 @@ Differences from the reference that a caller can observe are listed in DESIGN.md
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import warnings
 from abc import ABC
 from dataclasses import dataclass, fields, is_dataclass, replace
+from operator import attrgetter
 from typing import Any, Optional
 
 import numpy as np
@@ -106,8 +108,16 @@ class CoreEnvironment(ABC):
         # per-call launch options (excenv_launch_opts_t); None = library defaults. Tuning experiments only.
         self.launch_opts = None
         self._packed_props = None
+        self._packed_for = None
         self._flag_cache = {}
         self._obs_dim_cache = None
+        # vmap_step fast path (see _vmap_step_launch): output slots carved from one allocation per `n` calls, pointer arrays
+        # pre-built per slot, and the identity of the state we returned last (its pointer array is the next call's input)
+        self._slots = {False: None, True: None}
+        self._last_out = None
+        self._ctl_cache = None
+        self._active_additions = None
+        self._leaf_getter = None
 
     # ------------------------------------------------------------------ properties plumbing
     def create_in_axes_dataclass(self, dataclass_obj):
@@ -178,8 +188,9 @@ class CoreEnvironment(ABC):
 
     def _props_for(self, env_properties, B: int):
         if env_properties is self.env_properties and B == self.batch_size:
-            if self._packed_props is None:
+            if self._packed_props is None or self._packed_for is not env_properties:
                 self._packed_props = self._pack_props(env_properties, B)
+                self._packed_for = env_properties
             return self._packed_props
         return self._pack_props(env_properties, B)
 
@@ -379,48 +390,138 @@ class CoreEnvironment(ABC):
         new_state = replace(state, physical_state=new_phys, additions=self._additions((), True))
         return obs[0], new_state
 
+    # -- vmap_step fast path -------------------------------------------------------------------------------------------
+    # The reference's HOT LOOP #1 is a Python loop of vmap_step calls (README.md:28-32); at RL batch sizes the kernel takes
+    # a few microseconds, so the host side decides the rate. Per call this path does: identity check of the incoming state
+    # leaves (did we return them last time? then their pointer array is already built), one data_ptr() for the action, one
+    # ctypes call with pre-built arguments, two small dataclass constructions. Outputs are still fresh memory every call
+    # (functional contract): slots are carved from one allocation per `n` calls and never reused.
+    class _Slots:
+        __slots__ = ("n", "i", "leaves", "obs", "out_ptrs", "obs_ptrs", "gym", "gym_ptrs")
+
+    def _new_slots(self, n: int, gym: bool):
+        B, S, O = self.batch_size, self.physical_state_dim, self._obs_dim()
+        isz = torch.empty((), dtype=self.dtype).element_size()
+        al = 16 // isz
+        Bp = (B + al - 1) // al * al
+        obs_elems = (B * O + al - 1) // al * al
+        rew_elems = Bp if gym else 0
+        slot = S * Bp + obs_elems + rew_elems
+        buf = torch.empty(n * slot, dtype=self.dtype, device=self.device)
+        base = buf.data_ptr()
+        sl = CoreEnvironment._Slots()
+        sl.n, sl.i = n, 0
+        sl.leaves = [t.unbind(0) for t in buf.as_strided((n, S, B), (slot, Bp, 1)).unbind(0)]
+        sl.obs = buf.as_strided((n, B, O), (slot, O, 1), S * Bp).unbind(0)
+        sl.out_ptrs = [_native.ptr_array([base + (i * slot + j * Bp) * isz for j in range(S)]) for i in range(n)]
+        sl.obs_ptrs = [base + (i * slot + S * Bp) * isz for i in range(n)]
+        sl.gym = sl.gym_ptrs = None
+        if gym:
+            TW = _native.truncated_width(self.ENV_ID, len(self.control_state))
+            flags = torch.empty((n, B * (1 + TW)), dtype=torch.bool, device=self.device)
+            fbase = flags.data_ptr()
+            rew = buf.as_strided((n, B, 1), (slot, 1, 1), S * Bp + obs_elems).unbind(0)
+            term = flags.as_strided((n, B, 1), (B * (1 + TW), 1, 1)).unbind(0)
+            trunc = flags.as_strided((n, B, TW), (B * (1 + TW), TW, 1), B).unbind(0)
+            sl.gym = list(zip(rew, term, trunc))
+            sl.gym_ptrs = [(base + (i * slot + S * Bp + obs_elems) * isz, fbase + i * B * (1 + TW),
+                            fbase + i * B * (1 + TW) + B) for i in range(n)]
+        return sl
+
+    def _slots_per_alloc(self, gym: bool) -> int:
+        isz = 4 if self.dtype == torch.float32 else 8
+        per = self.batch_size * (self.physical_state_dim + self._obs_dim() + (1 if gym else 0)) * isz
+        return max(1, min(32, (4 << 20) // max(per, 1)))
+
+    def _vmap_step_launch(self, state, action, gym: bool):
+        B = self.batch_size
+        dev = self.device
+        getter = self._leaf_getter
+        if getter is None:
+            names = self.STATE_FIELDS
+            getter = self._leaf_getter = attrgetter(*names) if len(names) > 1 else (lambda ps, _g=attrgetter(names[0]): (_g(ps),))
+        leaves = getter(state.physical_state)
+        last = self._last_out
+        if last is not None and last[0] == tuple(map(id, leaves)):
+            in_ptrs = last[2]  # the state we returned last: its output pointer array is this call's input
+        else:
+            shape = tuple(torch.as_tensor(leaves[0]).shape) + (len(leaves),)
+            assert shape == (B, self.physical_state_dim), (
+                "The physical state needs to be of shape (batch_size, physical_state_dim) which is "
+                + f"{(B, self.physical_state_dim)}, but {shape} is given"
+            )
+            st_in = [self._t(l, (B,)) for l in leaves]
+            in_ptrs = _native._ptrs(st_in)
+            self._last_out = None
+        if action.dtype is not self.dtype or action.device != dev or not action.is_contiguous():
+            action = self._t(action, (B, self.action_dim))
+        _native._require_device(action, "vmap_step")
+        control_ref = None
+        if self.control_state:
+            refs = tuple(getattr(state.reference, n) for n in self.control_state)
+            cc = self._ctl_cache
+            key = (tuple(self.control_state), tuple(map(id, refs)))
+            if cc is None or cc[0] != key:
+                tens = [self._t(r, (B,)) for r in refs]
+                ctl = _native.make_control([self.STATE_FIELDS.index(n) for n in self.control_state], tens)
+                cc = self._ctl_cache = (key, refs, tens, ctl, ctypes.byref(ctl))
+            control_ref = cc[4]
+        props, _keep = self._props_for(self.env_properties, B)
+        capturing = torch._C._cuda_isCurrentStreamCapturing()
+        sl = None if capturing else self._slots[gym]
+        if sl is None or sl.i == sl.n or sl.obs[0].shape[1] != (self._obs_dim_cache[1] if self._obs_dim_cache and
+                                                                 self._obs_dim_cache[0] == len(self.control_state) else self._obs_dim()):
+            sl = self._new_slots(1 if capturing else self._slots_per_alloc(gym), gym)
+            if not capturing:  # memory allocated during capture belongs to the graph's pool: never handed out later
+                self._slots[gym] = sl
+        i = sl.i
+        sl.i = i + 1
+        opts = self.launch_opts
+        idx = dev.index
+        cur = torch._C._cuda_getDevice()
+        if idx is None:
+            idx = cur
+        args = (self.ENV_ID, self._solver.id, 0 if self.dtype is torch.float32 else 1, B, ctypes.byref(props), control_ref,
+                self.tau, in_ptrs, action.data_ptr(), sl.out_ptrs[i], sl.obs_ptrs[i],
+                None if opts is None else ctypes.byref(opts), idx, sl.gym_ptrs[i] if gym else None)
+        if idx == cur:
+            _native.step_raw(*args)
+        else:
+            with torch.cuda.device(dev):
+                _native.step_raw(*args)
+        new_leaves = sl.leaves[i]
+        if not capturing:
+            self._last_out = (tuple(map(id, new_leaves)), new_leaves, sl.out_ptrs[i])
+        add = self._active_additions
+        if add is None:
+            add = self._active_additions = self._additions((B,), True)
+        new_state = self.State(self.PhysicalState(*new_leaves), state.PRNGKey, add, state.reference)
+        if gym:
+            rew, term, trunc = sl.gym[i]
+            return sl.obs[i], rew, term, trunc, new_state
+        return sl.obs[i], new_state
+
     def vmap_step(self, state, action):
-        """One simulation step of all batch_size environments (core_env.py:533-569)."""
-        action = torch.as_tensor(action)
-        assert tuple(action.shape) == (self.batch_size, self.action_dim), (
+        """One simulation step of all batch_size environments (core_env.py:533-569): one fused HIP launch."""
+        if type(action) is not torch.Tensor:
+            action = torch.as_tensor(action)
+        assert action.shape == (self.batch_size, self.action_dim), (
             "The action needs to be of shape (batch_size, action_dim) which is "
             + f"{(self.batch_size, self.action_dim)}, but {tuple(action.shape)} is given"
         )
-        physical_state_shape = self._phys_shape(state.physical_state)
-        assert physical_state_shape == (self.batch_size, self.physical_state_dim), (
-            "The physical state needs to be of shape (batch_size, physical_state_dim) which is "
-            + f"{(self.batch_size, self.physical_state_dim)}, but {physical_state_shape} is given"
-        )
-        obs, st_out = self._run_step(state, action, self.env_properties, self.batch_size)
-        new_phys = self.PhysicalState(**dict(zip(self.STATE_FIELDS, st_out)))
-        new_state = replace(state, physical_state=new_phys, additions=self._additions((self.batch_size,), True))
-        return obs, new_state
+        return self._vmap_step_launch(state, action, False)
 
     def vmap_gym_step(self, state, action):
         """vmap_step fused with generate_reward / generate_terminated / generate_truncated in ONE launch — what
         GymWrapper.gym_step computes per step (gym_wrapper.py:88-130). Returns
         (obs [B,O], reward [B,1], terminated [B,1] bool, truncated [B,TW] bool, new_state)."""
-        action = torch.as_tensor(action)
-        assert tuple(action.shape) == (self.batch_size, self.action_dim), (
+        if type(action) is not torch.Tensor:
+            action = torch.as_tensor(action)
+        assert action.shape == (self.batch_size, self.action_dim), (
             "The action needs to be of shape (batch_size, action_dim) which is "
             + f"{(self.batch_size, self.action_dim)}, but {tuple(action.shape)} is given"
         )
-        B, S, O = self.batch_size, self.physical_state_dim, self._obs_dim()
-        props, keep = self._props_for(self.env_properties, B)
-        st_in = [self._t(getattr(state.physical_state, n), (B,)) for n in self.STATE_FIELDS]
-        act = self._t(action, (B, self.action_dim))
-        control, refs = self._control(state, (B,))
-        st_out = [torch.empty(B, dtype=self.dtype, device=self.device) for _ in range(S)]
-        obs = torch.empty((B, O), dtype=self.dtype, device=self.device)
-        reward = torch.empty((B, 1), dtype=self.dtype, device=self.device)
-        terminated = torch.empty((B, 1), dtype=torch.bool, device=self.device)
-        truncated = torch.empty((B, _native.truncated_width(self.ENV_ID, len(self.control_state))), dtype=torch.bool,
-                                device=self.device)
-        _native.gym_step(self.ENV_ID, self._solver.id, self.dtype, B, props, control, float(self.tau), st_in, act,
-                         st_out, obs, reward, terminated, truncated)
-        new_state = replace(state, physical_state=self.PhysicalState(**dict(zip(self.STATE_FIELDS, st_out))),
-                            additions=self._additions((B,), True))
-        return obs, reward, terminated, truncated, new_state
+        return self._vmap_step_launch(state, action, True)
 
     # ------------------------------------------------------------------ reward / truncated / terminated (torch mirrors)
     ANGLE_FIELDS: tuple = ()
@@ -628,6 +729,13 @@ class CoreEnvironment(ABC):
         last_state = replace(init_state, physical_state=self.PhysicalState(**dict(zip(self.STATE_FIELDS, last))),
                              additions=self._additions((B,), True))
         return obs, states, last_state
+
+    def make_stepper(self, n_steps: int = 1, graph: bool = False, gym: bool = False):
+        """In-place multi-step stepping with static buffers (opt-in; see stepper.Stepper): `n_steps` chained vmap_step
+        (gym=True: vmap_gym_step) launches per `run()`, eagerly with pre-built arguments or as one HIP-graph replay."""
+        from .stepper import Stepper
+
+        return Stepper(self, n_steps=n_steps, graph=graph, gym=gym)
 
     def new_actions_buffer(self, n_action_steps: int, layout: str = "lane_major"):
         """A (batch_size, n_action_steps, action_dim) tensor whose memory is lane-major ([K, A, B]); filling this

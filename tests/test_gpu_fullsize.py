@@ -168,8 +168,9 @@ def _full_length_run(env_name, solver, dtype, log2_batch, n_chunks, Kc, T, tau=N
       * every tile of the observation trajectory (and of last_state) equals the first one bit for bit,
       * last_state equals the final trajectory row and everything is finite,
       * the first tile matches the CPU oracle started from the same chunk-initial state: bit-exact for the trig-free
-        systems over the whole chunk, <= 1e-5 (normalised units) over the first 64 rows otherwise (longer horizons amplify
-        the <= 2 ulp sin/cos differences chaotically — measured in DESIGN.md §5, not gated).
+        systems over the whole chunk, |d| <= 1e-5 * (1 + |ref|) (normalised units: the allclose(rtol=1e-5, atol=1e-5) of the
+        other parity tests) over the first 64 rows otherwise (longer horizons amplify the <= 2 ulp sin/cos differences
+        chaotically — measured in DESIGN.md §5, not gated).
     Returns the total number of env-steps simulated."""
     B = 1 << log2_batch
     np_dt = np.float32 if dtype == torch.float32 else np.float64
@@ -206,7 +207,8 @@ def _full_length_run(env_name, solver, dtype, log2_batch, n_chunks, Kc, T, tau=N
             d = np.abs(got[:, :65].astype(np.float64) - o_ref[:, :65])
             for col in angle_cols:
                 d[..., col] = np.minimum(d[..., col], np.abs(2 - d[..., col]))
-            assert d.max() <= 1e-5, f"chunk {c}: {d.max()}"
+            excess = d - 1e-5 * (1.0 + np.abs(o_ref[:, :65]))
+            assert excess.max() <= 0, f"chunk {c}: max |d| {d.max()}, max over tolerance {excess.max()}"
         state = last
         steps += B * Kc
         del obs, states, actions

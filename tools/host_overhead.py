@@ -38,6 +38,27 @@ for name in ("PENDULUM", "PMSM"):
         g.replay()
     torch.cuda.synchronize()
     print(f"{name}: {(time.perf_counter() - t0) / (200 * 16) * 1e6:.1f} us per vmap_step inside a 16-step HIP graph")
+    for graph in (False, True):
+        stp = env.make_stepper(n_steps=16, graph=graph)
+        stp.reset(state)
+        for _ in range(5):
+            stp.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(300):
+            stp.run()
+        torch.cuda.synchronize()
+        print(f"{name}: {(time.perf_counter() - t0) / (300 * 16) * 1e6:.2f} us per step, Stepper(n_steps=16, graph={graph})")
+    from exciting_environments_amd import GymWrapper
+    gw = GymWrapper(env)
+    for _ in range(50):
+        gw.step(act)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        gw.step(act)
+    torch.cuda.synchronize()
+    print(f"{name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per GymWrapper.step (fused gym kernel, B=1024)")
 
 env = EnvironmentRegistry.PENDULUM.make(batch_size=1024, device="cuda:0")
 _, state = env.vmap_reset()
