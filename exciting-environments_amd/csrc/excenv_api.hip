@@ -262,6 +262,38 @@ int excenv_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
                              stream);
 }
 
+int excenv_rew_trunc_term(int env, int dtype, int64_t B, int64_t rows, const excenv_props_t* props,
+                          const excenv_control_t* control, const int64_t* ref_strides, const void* const* state_traj,
+                          int64_t state_env_stride, int64_t state_row_stride, void* reward, uint8_t* terminated,
+                          uint8_t* truncated, int out_layout, void* stream) {
+  if (int rc = check_common("excenv_rew_trunc_term", env, 0, dtype, B)) return rc;
+  if (rows < 1) { set_error("excenv_rew_trunc_term: rows must be >= 1 (row 0 is the initial state)"); return EXCENV_EINVAL; }
+  if (out_layout != EXCENV_LAYOUT_ENV_MAJOR && out_layout != EXCENV_LAYOUT_LANE_MAJOR) { set_error("excenv_rew_trunc_term: bad out_layout"); return EXCENV_EINVAL; }
+  if (!props || !state_traj || !truncated || (rows > 1 && (!reward || !terminated))) { set_error("excenv_rew_trunc_term: NULL argument"); return EXCENV_ENULL; }
+  if (int rc = check_control("excenv_rew_trunc_term", env, control)) return rc;
+  int trc;
+  const EnvVTable* t = table_for(env, props, &trc);
+  if (!t) return trc;
+  TrajGymCall gc{dtype, B, rows, props, control, ref_strides, state_traj, state_env_stride, state_row_stride, reward,
+                 terminated, truncated, out_layout, (hipStream_t)stream};
+  return t->traj_gym(gc);
+}
+
+int excenv_state_from_observation(int env, int dtype, int64_t B, const excenv_props_t* props, int32_t n_control,
+                                  const int32_t* control_idx, const void* obs, void* const* state_out,
+                                  void* const* reference_out, void* stream) {
+  if (int rc = check_common("excenv_state_from_observation", env, 0, dtype, B)) return rc;
+  if (n_control < 0 || n_control > EXCENV_MAX_CONTROL) { set_error("excenv_state_from_observation: bad n_control %d", n_control); return EXCENV_EINVAL; }
+  if (!props || !obs || !state_out || (n_control > 0 && (!control_idx || !reference_out))) { set_error("excenv_state_from_observation: NULL argument"); return EXCENV_ENULL; }
+  for (int j = 0; j < n_control; ++j)
+    if (control_idx[j] < 0 || control_idx[j] >= table_public(env)->S) { set_error("excenv_state_from_observation: control_idx[%d] out of range", j); return EXCENV_EINVAL; }
+  int trc;
+  const EnvVTable* t = table_for(env, props, &trc);
+  if (!t) return trc;
+  FromObsCall fc{dtype, B, props, n_control, control_idx, obs, state_out, reference_out, (hipStream_t)stream};
+  return t->from_obs(fc);
+}
+
 int excenv_probe_math(int which, int dtype, int64_t n, const void* in, void* out, void* stream) {
   if (which < 0 || which > 2 || n < 0 || (dtype != EXCENV_F32 && dtype != EXCENV_F64)) { set_error("excenv_probe_math: bad argument"); return EXCENV_EINVAL; }
   if (!in || !out) { set_error("excenv_probe_math: NULL argument"); return EXCENV_ENULL; }

@@ -520,6 +520,101 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   publish_last(sv);
 }
 
+// ---- generate_rew_trunc_term_ahead on a stored trajectory (core_env.py:490-531, 618-647) -----------------------------
+// One thread per (env, row) of the state trajectories a previous vmap_sim_ahead returned (any of its layouts: the host
+// passes element strides and says which of the two indices is the contiguous one). reward / terminated are written for
+// rows 1.. at index row-1, truncated for every row. References may vary along the trajectory (stride 0 = constant).
+template <typename T, class M> struct TrajGymArgs {
+  KProps<T, M> kp;
+  int64_t B, rows;
+  int32_t n_control, fast_is_env;
+  int32_t control_idx[EXCENV_MAX_CONTROL];
+  const T* reference[EXCENV_MAX_CONTROL];
+  int64_t r_sb[EXCENV_MAX_CONTROL], r_sk[EXCENV_MAX_CONTROL];
+  const T* straj[M::S];
+  int64_t s_sb, s_sk;
+  T* reward;
+  uint8_t* terminated;
+  uint8_t* truncated;
+  int64_t g_sb, g_sk, t_sb, t_sk, t_sc;
+};
+
+template <class M, typename T> __global__ void __launch_bounds__(BLOCK) traj_gym_kernel(const TrajGymArgs<T, M> ka) {
+  constexpr int S = M::S, O = M::O;
+  const int64_t nfast = ka.fast_is_env ? ka.B : ka.rows;
+  const int64_t nb_fast = (nfast + BLOCK - 1) / BLOCK;
+  const int64_t slow = (int64_t)blockIdx.x / nb_fast;
+  const int64_t fast = ((int64_t)blockIdx.x - slow * nb_fast) * BLOCK + threadIdx.x;
+  if (fast >= nfast) return;
+  const int64_t b = ka.fast_is_env ? fast : slow, n = ka.fast_is_env ? slow : fast;
+  Ctx<T, M> c;
+  load_ctx<true>(c, ka.kp, b, T(0), T(0), T(0));
+  T st[S], ob[O], rref[EXCENV_MAX_CONTROL];
+#pragma unroll
+  for (int j = 0; j < S; ++j) st[j] = ka.straj[j][b * ka.s_sb + n * ka.s_sk];
+#pragma unroll
+  for (int j = 0; j < EXCENV_MAX_CONTROL; ++j)
+    rref[j] = (j < ka.n_control) ? ka.reference[j][b * ka.r_sb[j] + n * ka.r_sk[j]] : T(0);
+  M::observe(st, c, ob);
+  const bool tail = n > 0;
+  gym_outputs<M, T>(st, ob, c, ka.n_control, ka.control_idx, rref, tail ? ka.reward + b * ka.g_sb + (n - 1) * ka.g_sk : nullptr,
+                    tail ? ka.terminated + b * ka.g_sb + (n - 1) * ka.g_sk : nullptr,
+                    ka.truncated + b * ka.t_sb + n * ka.t_sk, ka.t_sc);
+}
+
+// ---- generate_state_from_observation (e.g. pendulum_env.py:331-364; PMSM pmsm_env.py:921-970) -------------------------
+// obs [B][O + n_control] row-major -> S physical-state leaves [B] (denormalised) and the reference leaves of the
+// controlled fields. PMSM recovers eps from atan2(sin, cos) / pi before denormalising.
+template <typename T, class M> struct FromObsArgs {
+  KProps<T, M> kp;
+  int64_t B;
+  int32_t n_control;
+  int32_t control_idx[EXCENV_MAX_CONTROL];
+  const T* obs;
+  T* state_out[M::S];
+  T* reference_out[EXCENV_MAX_CONTROL];
+};
+
+__device__ __forceinline__ float xatan2(float y, float x) { return ::atan2f(y, x); }
+__device__ __forceinline__ double xatan2(double y, double x) { return ::atan2(y, x); }
+
+template <class M, typename T> __global__ void __launch_bounds__(BLOCK) from_obs_kernel(const FromObsArgs<T, M> ka) {
+  constexpr int S = M::S, O = M::O;
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= ka.B) return;
+  Ctx<T, M> c;
+  load_ctx<true>(c, ka.kp, i, T(0), T(0), T(0));
+  const T* row = ka.obs + i * (O + ka.n_control);
+  T nrm[S];
+  if constexpr (M::IS_PMSM) {  // obs = [i_d, i_q, omega_el, torque, cos eps, sin eps, u_d_buffer, u_q_buffer]
+    nrm[0] = row[6];
+    nrm[1] = row[7];
+    nrm[2] = xatan2(row[5], row[4]) / K<T>::pi;
+    nrm[3] = row[0];
+    nrm[4] = row[1];
+    nrm[5] = row[3];
+    nrm[6] = row[2];
+  } else {
+#pragma unroll
+    for (int j = 0; j < S; ++j) nrm[j] = row[j];
+  }
+#pragma unroll
+  for (int j = 0; j < S; ++j) ka.state_out[j][i] = denormalize(nrm[j], c.smin[j], c.smax[j]);
+#pragma unroll
+  for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+    if (j < ka.n_control) {
+      const int f = ka.control_idx[j];
+      T lo = c.smin[0], hi = c.smax[0];
+#pragma unroll
+      for (int q = 1; q < S; ++q) {
+        lo = (f == q) ? c.smin[q] : lo;
+        hi = (f == q) ? c.smax[q] : hi;
+      }
+      ka.reference_out[j][i] = denormalize(row[O + j], lo, hi);
+    }
+  }
+}
+
 // ---- probes for the in-kernel math (tests) ---------------------------------------------------
 template <typename T> __global__ void probe_kernel(int which, int64_t n, const T* in, T* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -60,10 +60,39 @@ static inline bool em_fused_eligible(int em_mode, int action_layout, int traj_la
          substeps == 1 && !with_gym && em_lds_elems<float>(A, OW, S, with_states) * elem <= 150 * 1024;
 }
 
+struct TrajGymCall {
+  int dtype;
+  int64_t B, rows;
+  const excenv_props_t* props;
+  const excenv_control_t* control;
+  const int64_t* ref_strides;  // [n_control][2] element strides (env, row) of each reference array
+  const void* const* state_traj;
+  int64_t s_sb, s_sk;  // element strides (env, row) of every state leaf
+  void* reward;
+  uint8_t* terminated;
+  uint8_t* truncated;
+  int out_layout;
+  hipStream_t stream;
+};
+
+struct FromObsCall {
+  int dtype;
+  int64_t B;
+  const excenv_props_t* props;
+  int32_t n_control;
+  const int32_t* control_idx;
+  const void* obs;
+  void* const* state_out;
+  void* const* reference_out;
+  hipStream_t stream;
+};
+
 struct EnvVTable {
   int S, A, O, P;
   int (*step)(const StepCall&);
   int (*sim)(const SimCall&);
+  int (*traj_gym)(const TrajGymCall&);
+  int (*from_obs)(const FromObsCall&);
 };
 
 template <typename T, class M>
@@ -402,6 +431,67 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   return check_launch("excenv_sim_ahead");
 }
 
+template <class M, typename T> static int launch_traj_gym(const TrajGymCall& gc) {
+  TrajGymArgs<T, M> ka;
+  std::memset(&ka, 0, sizeof(ka));
+  fill_props<T, M>(ka.kp, gc.props);
+  ka.B = gc.B;
+  ka.rows = gc.rows;
+  ka.n_control = gc.control ? gc.control->n_control : 0;
+  for (int j = 0; j < ka.n_control; ++j) {
+    ka.control_idx[j] = gc.control->control_idx[j];
+    ka.reference[j] = (const T*)gc.control->reference[j];
+    ka.r_sb[j] = gc.ref_strides ? gc.ref_strides[2 * j] : 1;
+    ka.r_sk[j] = gc.ref_strides ? gc.ref_strides[2 * j + 1] : 0;
+  }
+  for (int j = 0; j < M::S; ++j) {
+    if (!gc.state_traj[j]) { set_error("excenv_rew_trunc_term: state_traj pointer %d is NULL", j); return EXCENV_ENULL; }
+    ka.straj[j] = (const T*)gc.state_traj[j];
+  }
+  ka.s_sb = gc.s_sb;
+  ka.s_sk = gc.s_sk;
+  ka.reward = (T*)gc.reward;
+  ka.terminated = gc.terminated;
+  ka.truncated = gc.truncated;
+  const int64_t N = gc.rows - 1;
+  const int64_t TW = (M::IS_PMSM || M::ID == EXCENV_FLUID_TANK) ? 1 : M::O + ka.n_control;
+  if (gc.out_layout == EXCENV_LAYOUT_ENV_MAJOR) {
+    ka.g_sb = N; ka.g_sk = 1;
+    ka.t_sb = gc.rows * TW; ka.t_sk = TW; ka.t_sc = 1;
+  } else {
+    ka.g_sb = 1; ka.g_sk = gc.B;
+    ka.t_sb = 1; ka.t_sk = TW * gc.B; ka.t_sc = gc.B;
+  }
+  if (gc.B == 0 || gc.rows == 0) return EXCENV_OK;
+  ka.fast_is_env = (gc.s_sb == 1 || gc.rows == 1) ? 1 : 0;  // lanes run along the contiguous index of the state arrays
+  const int64_t nfast = ka.fast_is_env ? gc.B : gc.rows, nslow = ka.fast_is_env ? gc.rows : gc.B;
+  const int64_t blocks = ((nfast + BLOCK - 1) / BLOCK) * nslow;
+  if (blocks >= ((int64_t)1 << 31)) { set_error("excenv_rew_trunc_term: trajectory too large for one launch"); return EXCENV_EUNSUPPORTED; }
+  hipLaunchKernelGGL((traj_gym_kernel<M, T>), dim3((unsigned)blocks), dim3(BLOCK), 0, gc.stream, ka);
+  return check_launch("excenv_rew_trunc_term");
+}
+
+template <class M, typename T> static int launch_from_obs(const FromObsCall& fc) {
+  FromObsArgs<T, M> ka;
+  std::memset(&ka, 0, sizeof(ka));
+  fill_props<T, M>(ka.kp, fc.props);
+  ka.B = fc.B;
+  ka.n_control = fc.n_control;
+  ka.obs = (const T*)fc.obs;
+  for (int j = 0; j < M::S; ++j) {
+    if (!fc.state_out[j]) { set_error("excenv_state_from_observation: state_out pointer %d is NULL", j); return EXCENV_ENULL; }
+    ka.state_out[j] = (T*)fc.state_out[j];
+  }
+  for (int j = 0; j < fc.n_control; ++j) {
+    if (!fc.reference_out || !fc.reference_out[j]) { set_error("excenv_state_from_observation: reference_out pointer %d is NULL", j); return EXCENV_ENULL; }
+    ka.control_idx[j] = fc.control_idx[j];
+    ka.reference_out[j] = (T*)fc.reference_out[j];
+  }
+  if (fc.B == 0) return EXCENV_OK;
+  hipLaunchKernelGGL((from_obs_kernel<M, T>), dim3((unsigned)((fc.B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, fc.stream, ka);
+  return check_launch("excenv_state_from_observation");
+}
+
 template <template <typename> class MT> struct EnvEntry {
   static int step(const StepCall& sc) {
     return sc.dtype == EXCENV_F32 ? launch_step<MT<float>, float>(sc) : launch_step<MT<double>, double>(sc);
@@ -409,7 +499,15 @@ template <template <typename> class MT> struct EnvEntry {
   static int sim(const SimCall& sc) {
     return sc.dtype == EXCENV_F32 ? launch_sim<MT<float>, float>(sc) : launch_sim<MT<double>, double>(sc);
   }
-  static EnvVTable vtable() { return EnvVTable{MT<float>::S, MT<float>::A, MT<float>::O, MT<float>::P, &step, &sim}; }
+  static int traj_gym(const TrajGymCall& gc) {
+    return gc.dtype == EXCENV_F32 ? launch_traj_gym<MT<float>, float>(gc) : launch_traj_gym<MT<double>, double>(gc);
+  }
+  static int from_obs(const FromObsCall& fc) {
+    return fc.dtype == EXCENV_F32 ? launch_from_obs<MT<float>, float>(fc) : launch_from_obs<MT<double>, double>(fc);
+  }
+  static EnvVTable vtable() {
+    return EnvVTable{MT<float>::S, MT<float>::A, MT<float>::O, MT<float>::P, &step, &sim, &traj_gym, &from_obs};
+  }
 };
 
 }  // namespace excenv

@@ -89,7 +89,7 @@ def lib():
         l.excenv_sim_ahead_workspace_bytes.restype = ctypes.c_int64
         l.excenv_truncated_width.restype = ctypes.c_int32
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
-                   "excenv_probe_math"):
+                   "excenv_probe_math", "excenv_rew_trunc_term", "excenv_state_from_observation"):
             getattr(l, fn).restype = ctypes.c_int
         vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
         # typed prototypes: plain Python ints / floats / None / byref() pass without per-call ctypes wrapping
@@ -268,6 +268,35 @@ def sim_ahead(env_id, solver_id, dtype, B, K, substeps, props: Props, control: O
             _opts_ref(opts), ctypes.c_void_p(stream),
         )
     _check(rc, "excenv_sim_ahead")
+
+
+def rew_trunc_term(env_id, dtype, B, rows, props: Props, control: Optional[Control], ref_strides: Optional[Sequence[int]],
+                   state_traj: Sequence[torch.Tensor], s_sb: int, s_sk: int, reward: torch.Tensor, terminated: torch.Tensor,
+                   truncated: torch.Tensor, out_layout: int):
+    """excenv_rew_trunc_term: reward / terminated / truncated of a stored trajectory (one thread per (env, row))."""
+    _require_device(truncated, "vmap_generate_rew_trunc_term_ahead")
+    rs = (ctypes.c_int64 * len(ref_strides))(*ref_strides) if ref_strides else None
+    with _on_device(truncated.device):
+        rc = lib().excenv_rew_trunc_term(
+            ctypes.c_int(env_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B), ctypes.c_int64(rows), ctypes.byref(props),
+            ctypes.byref(control) if control is not None else None, rs, _ptrs(state_traj), ctypes.c_int64(s_sb),
+            ctypes.c_int64(s_sk), ctypes.c_void_p(reward.data_ptr() if rows > 1 else None),
+            ctypes.c_void_p(terminated.data_ptr() if rows > 1 else None), ctypes.c_void_p(truncated.data_ptr()),
+            ctypes.c_int(out_layout), ctypes.c_void_p(_raw_stream(truncated.device)))
+    _check(rc, "excenv_rew_trunc_term")
+
+
+def state_from_observation(env_id, dtype, B, props: Props, control_idx: Sequence[int], obs: torch.Tensor,
+                           state_out: Sequence[torch.Tensor], reference_out: Sequence[torch.Tensor]):
+    """excenv_state_from_observation: obs [B, O + n_control] -> denormalised state leaves (+ controlled reference leaves)."""
+    _require_device(obs, "vmap_generate_state_from_observation")
+    nc = len(control_idx)
+    with _on_device(obs.device):
+        rc = lib().excenv_state_from_observation(
+            ctypes.c_int(env_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B), ctypes.byref(props), ctypes.c_int32(nc),
+            (ctypes.c_int32 * nc)(*control_idx) if nc else None, ctypes.c_void_p(obs.data_ptr()), _ptrs(state_out),
+            _ptrs(reference_out) if nc else None, ctypes.c_void_p(_raw_stream(obs.device)))
+    _check(rc, "excenv_state_from_observation")
 
 
 def sim_ahead_workspace_bytes(env_id, dtype, B, K, substeps, n_control, action_layout, traj_layout,

@@ -304,8 +304,36 @@ class CoreEnvironment(ABC):
         return torch.stack(torch.broadcast_tensors(*cols), dim=-1)
 
     def generate_state_from_observation(self, obs, env_properties, key=None):
-        """e.g. pendulum_env.py:331-364."""
+        """e.g. pendulum_env.py:331-364. A [B', O] batch on the HIP device goes through one kernel
+        (excenv_state_from_observation); other shapes (a single observation, extra leading axes) and CPU tensors use the
+        elementwise torch mirror."""
         obs = self._t(obs)
+        if obs.ndim == 2 and obs.is_cuda and obs.shape[1] == self._obs_dim():
+            try:
+                props, keep = self._props_for(env_properties, obs.shape[0])
+            except ValueError:
+                props = None  # per-env property arrays of another batch size: broadcast semantics of the torch mirror
+            if props is not None:
+                return self._state_from_obs_device(obs, props, key)
+        return self._state_from_obs_torch(obs, env_properties, key)
+
+    def _state_from_obs_device(self, obs, props, key):
+        Bq, S = obs.shape[0], self.physical_state_dim
+        idx = [self.STATE_FIELDS.index(n) for n in self.control_state]
+        isz = obs.element_size()
+        al = 16 // isz
+        Bp = (Bq + al - 1) // al * al
+        buf = torch.empty((S + len(idx), Bp), dtype=self.dtype, device=self.device)
+        leaves = [buf[j, :Bq] for j in range(S)]
+        refs = [buf[S + j, :Bq] for j in range(len(idx))]
+        _native.state_from_observation(self.ENV_ID, self.dtype, Bq, props, idx, obs, leaves, refs)
+        ref = {n: self._nan((Bq,)) for n in self.STATE_FIELDS}
+        for n, r in zip(self.control_state, refs):
+            ref[n] = r
+        return self.State(physical_state=self.PhysicalState(*leaves), PRNGKey=self._nan((Bq,)) if key is None else key,
+                          additions=self._additions((Bq,), False), reference=self.PhysicalState(**ref))
+
+    def _state_from_obs_torch(self, obs, env_properties, key=None):
         shape = tuple(obs.shape[:-1])
         S = len(self.STATE_FIELDS)
         phys = {n: obs[..., j] for j, n in enumerate(self.STATE_FIELDS)}
@@ -548,8 +576,10 @@ class CoreEnvironment(ABC):
         return reward == 0
 
     def vmap_generate_rew_trunc_term_ahead(self, states, actions):
-        """core_env.py:618-647 / :490-531 for trajectories returned by vmap_sim_ahead (elementwise torch ops over
-        the [B, K+1] leaves): reward [B,K,1] on rows 1.., truncated on all rows, terminated on rows 1..."""
+        """core_env.py:618-647 / :490-531 for trajectories returned by vmap_sim_ahead: reward [B,K,1] on rows 1..,
+        truncated [B,K+1,TW] on all rows, terminated [B,K,1] on rows 1... One HIP launch over the stored trajectory
+        (excenv_rew_trunc_term; `vmap_sim_ahead(..., return_rew_trunc_term=True)` produces the same values inside the
+        trajectory launch itself). CPU tensors fall back to the elementwise torch mirror."""
         actions = torch.as_tensor(actions)
         assert actions.ndim == 3, "The actions need to have three dimensions: (batch_size, n_action_steps, action_dim)"
         assert (
@@ -558,6 +588,53 @@ class CoreEnvironment(ABC):
         assert (
             actions.shape[-1] == self.action_dim
         ), f"The last dimension does not correspond to the action dim which is {self.action_dim}, but {actions.shape[-1]} is given"
+        leaves = [torch.as_tensor(getattr(states.physical_state, n)) for n in self.STATE_FIELDS]
+        if leaves[0].is_cuda and leaves[0].ndim == 2 and leaves[0].shape[0] == self.batch_size:
+            return self._rew_trunc_term_device(states, leaves)
+        return self._rew_trunc_term_torch(states)
+
+    def _rew_trunc_term_device(self, states, leaves):
+        B, rows = leaves[0].shape
+        N = rows - 1
+        leaves = [l if (l.dtype == self.dtype and l.device == self.device) else l.to(device=self.device, dtype=self.dtype)
+                  for l in leaves]
+        strides = {tuple(l.stride()) for l in leaves}
+        if len(strides) != 1 or any(l.shape != (B, rows) for l in leaves):
+            leaves = [l.contiguous() for l in leaves]
+        s_sb, s_sk = leaves[0].stride()
+        lane_major = (s_sb == 1 and rows > 1)
+        props, keep = self._props_for(self.env_properties, B)
+        control, ref_strides, refs = None, None, []
+        if self.control_state:
+            idx = [self.STATE_FIELDS.index(n) for n in self.control_state]
+            ref_strides = []
+            for n in self.control_state:
+                r = torch.as_tensor(getattr(states.reference, n))
+                if not (r.is_cuda and r.dtype == self.dtype):
+                    r = r.to(device=self.device, dtype=self.dtype)
+                if r.ndim != 2 or tuple(r.shape) != (B, rows):
+                    r = r.reshape(B, -1).expand(B, rows) if r.ndim >= 1 else r.expand(B, rows)
+                refs.append(r)
+                ref_strides += list(r.stride())
+            control = _native.make_control(idx, refs)
+        TW = _native.truncated_width(self.ENV_ID, len(self.control_state))
+        if lane_major:  # outputs as [B, ., .] views over lane-major memory, like the trajectories themselves
+            rew_buf = torch.empty((max(N, 0), B), dtype=self.dtype, device=self.device)
+            term_buf = torch.empty((max(N, 0), B), dtype=torch.bool, device=self.device)
+            trunc_buf = torch.empty((rows, TW, B), dtype=torch.bool, device=self.device)
+            out = (rew_buf.t()[..., None], trunc_buf.permute(2, 0, 1), term_buf.t()[..., None])
+            layout = _native.LAYOUT_LANE_MAJOR
+        else:
+            rew_buf = torch.empty((B, max(N, 0), 1), dtype=self.dtype, device=self.device)
+            term_buf = torch.empty((B, max(N, 0), 1), dtype=torch.bool, device=self.device)
+            trunc_buf = torch.empty((B, rows, TW), dtype=torch.bool, device=self.device)
+            out = (rew_buf, trunc_buf, term_buf)
+            layout = _native.LAYOUT_ENV_MAJOR
+        _native.rew_trunc_term(self.ENV_ID, self.dtype, B, rows, props, control, ref_strides, leaves, s_sb, s_sk, rew_buf,
+                               term_buf, trunc_buf, layout)
+        return out
+
+    def _rew_trunc_term_torch(self, states):
         props = self._traj_properties()
         cut = lambda tree: replace(tree, physical_state=self.PhysicalState(**{n: getattr(tree.physical_state, n)[:, 1:] for n in self.STATE_FIELDS}),
                                    reference=self.PhysicalState(**{n: getattr(tree.reference, n)[:, 1:] for n in self.STATE_FIELDS}))
@@ -598,7 +675,7 @@ class CoreEnvironment(ABC):
                 f"(floating-point floor); returning the intended {K * sub + 1} rows", RuntimeWarning)
         return sub
 
-    def _run_sim_ahead(self, init_state, actions, env_properties, obs_stepsize, action_stepsize, B):
+    def _run_sim_ahead(self, init_state, actions, env_properties, obs_stepsize, action_stepsize, B, want_gym=False):
         S, A, OW = self.physical_state_dim, self.action_dim, self._obs_dim()
         actions = torch.as_tensor(actions)
         K = actions.shape[-2]
@@ -656,8 +733,27 @@ class CoreEnvironment(ABC):
         opts = self.launch_opts
         if _native.LAYOUT_ENV_MAJOR in (a_layout, t_layout) and not self.env_major_fused:
             opts = _native.launch_opts(opts.envs_per_lane if opts else 0, 1, opts.lds_pad_bytes if opts else 0)
+        gym_bufs = gym_out = None
+        if want_gym:  # reward / terminated / truncated trajectories from the same launch (excenv_traj_gym_t)
+            if t_layout == _native.LAYOUT_TILED:
+                raise ValueError("return_rew_trunc_term is not available with traj_layout='tiled'")
+            TW = _native.truncated_width(self.ENV_ID, len(self.control_state))
+            if t_layout == _native.LAYOUT_LANE_MAJOR:
+                rew = torch.empty((N, B), dtype=self.dtype, device=self.device)
+                term = torch.empty((N, B), dtype=torch.bool, device=self.device)
+                trunc = torch.empty((N + 1, TW, B), dtype=torch.bool, device=self.device)
+                gym_out = (rew.t()[..., None], trunc.permute(2, 0, 1), term.t()[..., None])
+            else:
+                rew = torch.empty((B, N, 1), dtype=self.dtype, device=self.device)
+                term = torch.empty((B, N, 1), dtype=torch.bool, device=self.device)
+                trunc = torch.empty((B, N + 1, TW), dtype=torch.bool, device=self.device)
+                gym_out = (rew, trunc, term)
+            gym_bufs = (rew, term, trunc)
         _native.sim_ahead(self.ENV_ID, self._solver.id, self.dtype, B, K, sub, props, control, float(obs_stepsize),
-                          float(self.tau), st_in, actions, a_layout, obs_buf, st_buf, t_layout, last, sem, workspace, opts)
+                          float(self.tau), st_in, actions, a_layout, obs_buf, st_buf, t_layout, last, sem, workspace, opts,
+                          gym_bufs)
+        if want_gym:
+            return observations, st_views, last, N, gym_out
         return observations, st_views, last, N
 
     def _traj_state(self, init_state, st_views, lead_shape, N):
@@ -695,10 +791,14 @@ class CoreEnvironment(ABC):
             **{n: t.reshape(()) for n, t in zip(self.STATE_FIELDS, last)}), additions=self._additions((), True))
         return obs[0], states, last_state
 
-    def vmap_sim_ahead(self, init_state, actions, obs_stepsize, action_stepsize):
+    def vmap_sim_ahead(self, init_state, actions, obs_stepsize, action_stepsize, return_rew_trunc_term=False):
         """Trajectories of all batch_size environments in one persistent kernel launch (core_env.py:571-616):
         actions (batch_size, n_action_steps, action_dim) -> observations (batch_size, n+1, obs_dim), states with
-        leaves (batch_size, n+1), last_state with leaves (batch_size,)."""
+        leaves (batch_size, n+1), last_state with leaves (batch_size,).
+
+        return_rew_trunc_term=True (extension): the same launch also evaluates what
+        vmap_generate_rew_trunc_term_ahead(states, actions) would (core_env.py:618-647) and the call returns
+        (observations, states, last_state, reward [B,n,1], truncated [B,n+1,TW], terminated [B,n,1])."""
         assert (
             obs_stepsize <= action_stepsize
         ), "The action stepsize should be greater or equal to the observation stepsize."
@@ -717,8 +817,13 @@ class CoreEnvironment(ABC):
             + f"{(self.batch_size, self.physical_state_dim)}, but {init_physical_state_shape} is given"
         )
         B = self.batch_size
-        obs, st_views, last, N = self._run_sim_ahead(init_state, actions, self.env_properties, obs_stepsize,
-                                                     action_stepsize, B)
+        gym_out = None
+        if return_rew_trunc_term:
+            obs, st_views, last, N, gym_out = self._run_sim_ahead(init_state, actions, self.env_properties, obs_stepsize,
+                                                                  action_stepsize, B, want_gym=True)
+        else:
+            obs, st_views, last, N = self._run_sim_ahead(init_state, actions, self.env_properties, obs_stepsize,
+                                                         action_stepsize, B)
         if st_views is None:
             states = None
         elif self.traj_layout == "tiled":
@@ -728,6 +833,8 @@ class CoreEnvironment(ABC):
             states = self._traj_state(init_state, st_views, (B,), N)
         last_state = replace(init_state, physical_state=self.PhysicalState(**dict(zip(self.STATE_FIELDS, last))),
                              additions=self._additions((B,), True))
+        if gym_out is not None:
+            return (obs, states, last_state) + tuple(gym_out)
         return obs, states, last_state
 
     def make_stepper(self, n_steps: int = 1, graph: bool = False, gym: bool = False):

@@ -423,9 +423,8 @@ class PMSM(CoreEnvironment):
         cols += [getattr(ns.reference, n) for n in self.control_state]
         return torch.stack(torch.broadcast_tensors(*cols), dim=-1)
 
-    def generate_state_from_observation(self, obs, env_properties, key=None):
-        """pmsm_env.py:921-970."""
-        obs = self._t(obs)
+    def _state_from_obs_torch(self, obs, env_properties, key=None):
+        """pmsm_env.py:921-970 (elementwise torch mirror; device batches go through the kernel, core_env.py)."""
         shape = tuple(obs.shape[:-1])
         phys = dict(u_d_buffer=obs[..., 6], u_q_buffer=obs[..., 7],
                     epsilon=torch.atan2(obs[..., 5], obs[..., 4]) / math.pi, i_d=obs[..., 0], i_q=obs[..., 1],

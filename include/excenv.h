@@ -214,6 +214,27 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
 /* out[n][m] = in[m][n] for a row-major M x N matrix of the given dtype (the conversion kernel used above). */
 int excenv_transpose(int dtype, int64_t M, int64_t N, const void* in, void* out, void* stream);
 
+/* ---- replaces CoreEnvironment.vmap_generate_rew_trunc_term_ahead (core_env.py:490-531, 618-647) for a trajectory that
+ * is already in memory (the fused form is the `gym` argument of excenv_sim_ahead): one thread per (env, row).
+ *   state_traj : S pointers to [B x rows] arrays with element strides (state_env_stride, state_row_stride) — any layout
+ *                excenv_sim_ahead writes (lane-major: (1, B); env-major: (rows, 1))
+ *   control    : reference[j] is the base of the reference values of field control_idx[j]; ref_strides[2j], [2j+1] are its
+ *                element strides (env, row) — (1, 0) for a reference that is constant along the trajectory; NULL = (1, 0)
+ *   reward     : rows-1 values per env (rows 1..), terminated: rows-1 bytes, truncated: rows x excenv_truncated_width bytes,
+ *                laid out as `out_layout` (EXCENV_LAYOUT_ENV_MAJOR [B][row][flag] or EXCENV_LAYOUT_LANE_MAJOR [row][flag][B]) */
+int excenv_rew_trunc_term(int env, int dtype, int64_t B, int64_t rows, const excenv_props_t* props,
+                          const excenv_control_t* control, const int64_t* ref_strides, const void* const* state_traj,
+                          int64_t state_env_stride, int64_t state_row_stride, void* reward, uint8_t* terminated,
+                          uint8_t* truncated, int out_layout, void* stream);
+
+/* ---- replaces CoreEnvironment.vmap_generate_state_from_observation (core_env.py:689-705; per env e.g.
+ * pendulum_env.py:331-364, pmsm_env.py:921-970): obs [B][O + n_control] row-major -> denormalised physical state leaves
+ * state_out[S][B] and, for each controlled field control_idx[j], its denormalised reference leaf reference_out[j][B]
+ * (the other reference leaves are NaN by definition and are not written here). */
+int excenv_state_from_observation(int env, int dtype, int64_t B, const excenv_props_t* props, int32_t n_control,
+                                  const int32_t* control_idx, const void* obs, void* const* state_out,
+                                  void* const* reference_out, void* stream);
+
 /* ---- device-math probes (tests only): out[i] = f(in[i]) for the in-kernel fp32 routines -- */
 int excenv_probe_math(int which /*0 sin,1 cos,2 wrap_angle*/, int dtype, int64_t n,
                       const void* in, void* out, void* stream);

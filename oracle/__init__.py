@@ -267,6 +267,31 @@ def sim_ahead(env: str, solver: str, state: Sequence[np.ndarray], actions: np.nd
     return obs, straj, last
 
 
+def rew_trunc_term_ahead(env: str, states: Sequence[np.ndarray], props: Props, control=None):
+    """generate_rew_trunc_term_ahead (core_env.py:490-531) on trajectories states[j] [B, rows] (env-major):
+    returns (reward [B, rows-1, 1], truncated [B, rows, TW] bool, terminated [B, rows-1, 1] bool)."""
+    dtype = np.dtype(states[0].dtype)
+    B, rows = states[0].shape
+    eid = ENV_IDS[env]
+    S, A, O, _ = ENV_DIMS[eid]
+    keep: list = []
+    ctl = _make_control(env, control, dtype, B, keep)
+    nc = len(control) if control else 0
+    TW = 1 if env in ("pmsm", "fluid_tank") else O + nc
+    st = [np.ascontiguousarray(s, dtype=dtype) for s in states]
+    reward = np.empty((B, rows), dtype=dtype)
+    term = np.empty((B, rows), dtype=np.uint8)
+    trunc = np.empty((B, rows, TW), dtype=np.uint8)
+    lib().oracle_rew_trunc_term.restype = ctypes.c_int
+    rc = lib().oracle_rew_trunc_term(
+        ctypes.c_int(eid), ctypes.c_int(DTYPE_IDS[dtype]), ctypes.c_int64(B), ctypes.c_int64(rows), ctypes.byref(props),
+        ctypes.byref(ctl) if ctl else None, _ptr_array(st), ctypes.c_void_p(reward.ctypes.data),
+        ctypes.c_void_p(term.ctypes.data), ctypes.c_void_p(trunc.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"oracle_rew_trunc_term failed rc={rc}")
+    return reward[:, 1:, None], trunc.astype(bool), term.astype(bool)[:, 1:, None]
+
+
 def denormalize(x, lo, hi):
     """utils.py:16-17 on host arrays (used to bootstrap a state from a stored observation)."""
     return (x + 1) / 2 * (hi - lo) + lo
@@ -275,11 +300,13 @@ def denormalize(x, lo, hi):
 def state_from_observation(env: str, obs0: np.ndarray, phys_norm: dict):
     """generate_state_from_observation (e.g. pendulum_env.py:331-364; pmsm_env.py:921-970) for one stored row."""
     f = STATE_FIELDS[env]
+    obs0 = np.asarray(obs0)  # one row [O] or a batch [..., O]
     if env == "pmsm":
         normed = {
-            "u_d_buffer": obs0[6], "u_q_buffer": obs0[7], "epsilon": np.arctan2(obs0[5], obs0[4]) / np.pi,
-            "i_d": obs0[0], "i_q": obs0[1], "torque": obs0[3], "omega_el": obs0[2],
+            "u_d_buffer": obs0[..., 6], "u_q_buffer": obs0[..., 7],
+            "epsilon": np.arctan2(obs0[..., 5], obs0[..., 4]) / np.asarray(np.pi, dtype=obs0.dtype),
+            "i_d": obs0[..., 0], "i_q": obs0[..., 1], "torque": obs0[..., 3], "omega_el": obs0[..., 2],
         }
     else:
-        normed = {name: obs0[j] for j, name in enumerate(f)}
+        normed = {name: obs0[..., j] for j, name in enumerate(f)}
     return [np.asarray(denormalize(normed[name], *phys_norm[name])) for name in f]

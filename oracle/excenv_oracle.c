@@ -149,6 +149,20 @@ int oracle_gym_step(int env, int solver, int dtype, int64_t B, const excenv_prop
                                                    obs, reward, terminated, truncated);
 }
 
+/* host-pointer twin of excenv_rew_trunc_term (env-major trajectories) */
+int oracle_rew_trunc_term(int env, int dtype, int64_t B, int64_t rows, const excenv_props_t* props,
+                          const excenv_control_t* control, const void* const* state_traj, void* reward,
+                          uint8_t* terminated, uint8_t* truncated) {
+  int rc = check_common(env, 0, dtype, B);
+  if (rc) return rc;
+  if (rows < 0) return EXCENV_EINVAL;
+  if (!props || !state_traj || !reward || !terminated || !truncated) return EXCENV_ENULL;
+  if (control && control->n_control == 0) control = NULL;
+  return dtype == EXCENV_F32
+             ? oracle_rew_trunc_term_f32(&ENVS[env], B, rows, props, control, state_traj, reward, terminated, truncated)
+             : oracle_rew_trunc_term_f64(&ENVS[env], B, rows, props, control, state_traj, reward, terminated, truncated);
+}
+
 /* host-pointer twin of excenv_sim_ahead */
 int oracle_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32_t substeps,
                      const excenv_props_t* props, const excenv_control_t* control, double obs_stepsize,

@@ -116,3 +116,103 @@ def test_vmap_generate_rew_trunc_term_ahead_shapes():
     th = states.physical_state.theta[:, 1:]
     want = -((torch.sin(th) - np.sin(0.5)) ** 2 + (torch.cos(th) - np.cos(0.5)) ** 2)
     assert torch.allclose(reward[..., 0], want, atol=1e-6)
+
+
+# ------------------------------------------------------------ trajectories: fused into the sim_ahead launch / stored
+@pytest.mark.parametrize("layout", ["lane_major", "env_major"])
+@pytest.mark.parametrize("semantics", ["step", "ahead"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("env_name", ENV_NAMES)
+def test_sim_ahead_fused_rew_trunc_term_matches_oracle(env_name, dtype, semantics, layout):
+    """vmap_sim_ahead(..., return_rew_trunc_term=True): reward / truncated / terminated trajectories out of the trajectory
+    launch itself (core_env.py:490-531) vs the oracle's literal restatement evaluated on the returned states, and vs the
+    stand-alone launch behind vmap_generate_rew_trunc_term_ahead (same device function: identical bits)."""
+    B, K = 700, 24
+    cs = CONTROL[env_name]
+    env, props, spec, st, refs, _ = _problem(env_name, B, dtype, cs, seed=231)
+    env.sim_ahead_semantics, env.traj_layout = semantics, layout
+    acts = np.random.default_rng(232).uniform(-1, 1, (B, K, env.action_dim)).astype(NP_DTYPE[dtype])
+    state = to_state(env, st, reference=refs)
+    a_dev = torch.as_tensor(acts, device=env.device)
+    obs, states, last, reward, truncated, terminated = env.vmap_sim_ahead(state, a_dev, env.tau, env.tau, return_rew_trunc_term=True)
+    obs2, states2, last2 = env.vmap_sim_ahead(state, a_dev, env.tau, env.tau)
+    assert torch.equal(obs, obs2)  # asking for the extra outputs does not change the trajectory
+    TW = 1 if env_name in ("pmsm", "fluid_tank") else obs.shape[-1]
+    assert reward.shape == (B, K, 1) and terminated.shape == (B, K, 1) and truncated.shape == (B, K + 1, TW)
+    st_np = [getattr(states.physical_state, n).cpu().numpy() for n in env.STATE_FIELDS]
+    control = [(n, refs[n]) for n in cs]
+    r_ref, tr_ref, te_ref = oracle.rew_trunc_term_ahead(env_name, st_np, props, control=control)
+    tol = 0.0 if env_name in TRIG_FREE else (1e-9 if dtype == torch.float64 else 2e-5)
+    if tol == 0.0:
+        assert np.array_equal(reward.cpu().numpy(), r_ref)
+    else:
+        assert np.allclose(reward.cpu().numpy(), r_ref, rtol=tol, atol=tol)
+    assert np.array_equal(truncated.cpu().numpy(), tr_ref) and np.array_equal(terminated.cpu().numpy(), te_ref)
+    if env_name != "fluid_tank":
+        assert bool(truncated.any()) and not bool(truncated.all())
+    r2, tr2, te2 = env.vmap_generate_rew_trunc_term_ahead(states, a_dev)
+    assert torch.equal(r2, reward) and torch.equal(tr2, truncated) and torch.equal(te2, terminated)
+    # contiguous copies of the state leaves (the reference's row-major arrays) take the other index order in the kernel
+    import dataclasses
+    states_c = dataclasses.replace(states, physical_state=env.PhysicalState(
+        **{n: getattr(states.physical_state, n).contiguous() for n in env.STATE_FIELDS}))
+    r3, tr3, te3 = env.vmap_generate_rew_trunc_term_ahead(states_c, a_dev)
+    assert torch.equal(r3, reward) and torch.equal(tr3, truncated) and torch.equal(te3, terminated)
+
+
+def test_rew_trunc_term_ahead_without_control_and_per_env_properties():
+    B, K = 300, 9
+    spec = spec_of("pendulum")
+    spec["params"]["l"] = np.random.default_rng(3).uniform(1.0, 3.0, B)
+    spec["phys_norm"]["omega"] = (-np.random.default_rng(4).uniform(5, 12, B), np.random.default_rng(4).uniform(5, 12, B))
+    env, props, keep, spec = make_env("pendulum", B, torch.float32, spec=spec)
+    st = random_state("pendulum", B, np.float32, spec_of("pendulum"), seed=5)
+    st[1][::2] *= 3.0
+    acts = torch.as_tensor(np.random.default_rng(6).uniform(-1, 1, (B, K, 1)).astype(np.float32), device=env.device)
+    obs, states, last, reward, truncated, terminated = env.vmap_sim_ahead(to_state(env, st), acts, env.tau, env.tau,
+                                                                        return_rew_trunc_term=True)
+    assert bool((reward == 0).all()) and bool(terminated.all())  # empty control_state: reward 0, terminated = (reward == 0)
+    assert torch.equal(truncated, obs.abs() > 1) and bool(truncated.any())
+    st_np = [getattr(states.physical_state, n).cpu().numpy() for n in env.STATE_FIELDS]
+    r_ref, tr_ref, te_ref = oracle.rew_trunc_term_ahead("pendulum", st_np, props)
+    assert np.array_equal(truncated.cpu().numpy(), tr_ref) and np.array_equal(terminated.cpu().numpy(), te_ref)
+
+
+# ------------------------------------------------------------ generate_state_from_observation on the device
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("env_name", ENV_NAMES)
+def test_state_from_observation_kernel_round_trip_and_oracle(env_name, dtype):
+    """vmap_generate_state_from_observation as one HIP launch: the reference's obs -> state -> obs round trip
+    (tests/envs/test_core_functions.py:55-77) and the oracle's restatement (pendulum_env.py:331-364, pmsm_env.py:921-970)."""
+    B = 1037
+    cs = CONTROL[env_name][:2]
+    env, props, spec, st, refs, act = _problem(env_name, B, dtype, cs, seed=241)
+    state = to_state(env, st, reference=refs)
+    obs = env.generate_observation(state, env.env_properties)
+    assert obs.is_cuda and obs.shape == (B, len(env.obs_description))
+    back = env.vmap_generate_state_from_observation(obs)
+    assert type(back) == env.State and bool(torch.isnan(back.PRNGKey).all()) and not bool(back.additions.active_solver_state.any())
+    want = oracle.state_from_observation(env_name, obs.cpu().numpy(), spec["phys_norm"])
+    for j, n in enumerate(env.STATE_FIELDS):
+        got = getattr(back.physical_state, n).cpu().numpy()
+        if env_name == "pmsm" and n == "epsilon":  # atan2 of (sin, cos): device library vs libm
+            tol = 1e-12 if dtype == torch.float64 else 2e-6
+            assert np.allclose(got, want[j], rtol=0, atol=tol)
+            assert np.allclose(got, st[j], rtol=0, atol=1e-9 if dtype == torch.float64 else 5e-6)
+        else:
+            assert np.array_equal(got, want[j]), n
+    for n in env.STATE_FIELDS:
+        r = getattr(back.reference, n)
+        if n in cs:
+            lo, hi = spec["phys_norm"][n]
+            pos = len(env.STATE_FIELDS) + cs.index(n) if env_name != "pmsm" else 8 + cs.index(n)
+            assert np.array_equal(r.cpu().numpy(), oracle.denormalize(obs[:, pos].cpu().numpy(), NP_DTYPE[dtype](lo), NP_DTYPE[dtype](hi))), n
+        else:
+            assert bool(torch.isnan(r).all())
+    obs2 = env.generate_observation(back, env.env_properties)
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    assert torch.allclose(obs2, obs, rtol=0, atol=tol)
+    # the torch mirror (single observation, CPU) agrees with the kernel
+    one = env.generate_state_from_observation(obs[5], env.env_properties)
+    for n in env.STATE_FIELDS:
+        assert torch.allclose(getattr(one.physical_state, n), getattr(back.physical_state, n)[5], rtol=0, atol=tol * 1e3)
