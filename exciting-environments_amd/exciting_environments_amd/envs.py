@@ -371,16 +371,15 @@ class PMSM(CoreEnvironment):
             key_leaf = None
             if _random.is_key(rng):
                 # pmsm_env.py:403-406: rng, subkey = split(rng); uniform(subkey, (2,), -1, 1); rng, subkey = split(rng);
-                # ball(subkey, 2). eps / omega follow the key stream; jax.random.ball (gamma rejection sampling) is not
-                # restated: the disc point is drawn from two further uniform words of the second subkey.
+                # ball(subkey, 2) — the whole draw follows the key stream (random.ball restates jax.random.ball's
+                # gamma-rejection construction; parity unpinned, see random.py).
                 k = rng.to(self.device)
                 assert tuple(k.shape[:-1]) == tuple(shape), f"rng keys must have shape {tuple(shape) + (2,)}"
                 s1 = _random.split(k)
                 sn = _random.uniform(s1[..., 1, :], 2, self.dtype, -1.0, 1.0)
                 s2 = _random.split(s1[..., 0, :])
-                w = _random.uniform(s2[..., 1, :], 2, self.dtype, 0.0, 1.0)
                 state_norm = [sn[..., 0], sn[..., 1]]
-                r, phi = torch.sqrt(w[..., 0]), w[..., 1] * (2 * math.pi)
+                disc = _random.ball(s2[..., 1, :].reshape(-1, 2), 2, 2, self.dtype).reshape(tuple(shape) + (2,))
                 key_leaf = s2[..., 0, :]
             else:
                 gen = rng
@@ -389,10 +388,11 @@ class PMSM(CoreEnvironment):
                     gen.manual_seed(int(rng))
                 u = lambda: torch.rand(shape, generator=gen, dtype=self.dtype, device=self.device)
                 state_norm = [u() * 2 - 1, u() * 2 - 1]
-                r, phi = torch.sqrt(u()), u() * (2 * math.pi)  # uniform in the unit disc (jax.random.ball(key, 2))
+                r, phi = torch.sqrt(u()), u() * (2 * math.pi)  # uniform in the unit disc (own stream)
+                disc = torch.stack([r * torch.cos(phi), r * torch.sin(phi)], dim=-1)
             (d_lo, d_hi), (q_lo, q_hi) = lo_hi("i_d"), lo_hi("i_q")
             i_max = torch.as_tensor(max(abs(float(torch.as_tensor(v).max())) for v in (d_lo, d_hi, q_lo, q_hi)))
-            i_d, i_q = r * torch.cos(phi) * i_max, r * torch.sin(phi) * i_max
+            i_d, i_q = disc[..., 0] * i_max, disc[..., 1] * i_max
             relu = torch.nn.functional.relu
             i_d = i_d - 2 * relu(i_d - d_hi) + 2 * relu(-i_d + d_lo)
             i_q = i_q - 2 * relu(i_q - q_hi) + 2 * relu(-i_q + q_lo)

@@ -1,14 +1,16 @@
 """GymWrapper — host-side mirror of reference exciting_environments/gym_wrapper.py: a stateful wrapper whose
 ``step(action)`` returns ``(observation, reward, terminated, truncated)``. The per-step work (ODE step + reward +
 terminated + truncated) is ONE fused HIP launch (``excenv_gym_step``). The reference-trajectory generator
-(``update_ref`` / ``generate_new_ref``, gym_wrapper.py:170-192) draws from ``torch`` generators, not JAX's Threefry
-stream, so reference values differ from the reference's for the same seed (deviations)."""
+(``update_ref`` / ``generate_new_ref``, gym_wrapper.py:170-192) has two modes: ``reset(rng_ref=<key tensor>)`` follows the
+reference's per-environment key stream (state.PRNGKey -> init_state -> split -> randint, restated in ``random.py``; parity
+unpinned), ``reset(rng_ref=<int | torch.Generator>)`` draws from a torch generator (own stream)."""
 from __future__ import annotations
 
 from dataclasses import fields, replace
 
 import torch
 
+from . import random as _random
 from .registration import EnvironmentRegistry
 
 
@@ -76,11 +78,21 @@ class GymWrapper:
         else:
             _, state = env.vmap_reset(rng_env)
         if rng_ref is not None:
-            gen = rng_ref
-            if not isinstance(rng_ref, torch.Generator):
-                gen = torch.Generator(device=env.device)
-                gen.manual_seed(int(rng_ref))
-            self._ref_rng = gen
+            if _random.is_key(rng_ref):
+                # gym_wrapper.py:149-155: one key -> split(rng_ref, batch_size); [B, 2] keys are taken as they are. The
+                # keys live in state.PRNGKey and advance with every new reference (generate_new_ref).
+                keys = rng_ref.to(env.device)
+                if keys.ndim == 1:
+                    keys = _random.split(keys, env.batch_size)
+                assert keys.shape[0] == env.batch_size
+                state = replace(state, PRNGKey=keys)
+                self._ref_rng = None
+            else:
+                gen = rng_ref
+                if not isinstance(rng_ref, torch.Generator):
+                    gen = torch.Generator(device=env.device)
+                    gen.manual_seed(int(rng_ref))
+                self._ref_rng = gen
             self.ref_gen = True
             need = torch.ones((env.batch_size, 1), dtype=torch.bool, device=env.device)
             state, self.reference_hold_steps = self.generate_new_ref(state, need, self.reference_hold_steps)
@@ -96,15 +108,23 @@ class GymWrapper:
         return state, hold_steps - 1
 
     def generate_new_ref(self, state, mask, hold_steps):
-        """gym_wrapper.py:177-192: reference := a random initial state's controlled fields; hold ~ U{min..max-1}."""
+        """gym_wrapper.py:177-192 for the environments selected by `mask` [B,1]: reference := the controlled fields of a random
+        initial state; hold ~ randint(hold_steps_min, hold_steps_max). Key mode (state.PRNGKey holds [B,2] keys):
+        init = init_state(PRNGKey); key, subkey = split(init.PRNGKey); hold = randint(subkey, (1,), min, max); PRNGKey = key."""
         env = self.env
-        init = env.vmap_init_state(self._ref_rng)
         m = mask[:, 0]
         ref = {n: getattr(state.reference, n) for n in env.STATE_FIELDS}
+        lo, hi = self.ref_params["hold_steps_min"], self.ref_params["hold_steps_max"]
+        if self._ref_rng is None and _random.is_key(state.PRNGKey):
+            init = env.vmap_init_state(state.PRNGKey)
+            sp = _random.split(init.PRNGKey)
+            new_hold = _random.randint(sp[:, 1, :], 1, lo, hi).to(hold_steps.dtype)
+            state = replace(state, PRNGKey=torch.where(mask, sp[:, 0, :], state.PRNGKey.to(sp.device)))
+        else:
+            init = env.vmap_init_state(self._ref_rng)
+            new_hold = torch.randint(lo, hi, (env.batch_size, 1), generator=self._ref_rng, device=env.device)
         for name in self.control_state:
             ref[name] = torch.where(m, getattr(init.physical_state, name), ref[name])
-        new_hold = torch.randint(self.ref_params["hold_steps_min"], self.ref_params["hold_steps_max"],
-                                 (env.batch_size, 1), generator=self._ref_rng, device=env.device)
         return replace(state, reference=env.PhysicalState(**ref)), torch.where(mask, new_hold, hold_steps)
 
     def render(self, *_, **__):

@@ -87,3 +87,118 @@ def uniform(key: torch.Tensor, n: int, dtype=torch.float32, minval=0.0, maxval=1
 
 def is_key(x) -> bool:
     return isinstance(x, torch.Tensor) and x.dtype in (torch.int64, torch.int32, torch.uint32) and x.ndim >= 1 and x.shape[-1] == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# jax.random.randint / ball and the samplers ball is built from (normal, exponential, gamma, rademacher), restated from
+# JAX's published source (jax/_src/random.py) as recalled — PARITY UNPINNED like the wiring above: no JAX is available to
+# check a single value against. What IS guaranteed by construction: every function consumes exactly the key it is given
+# (no hidden state), so the key STREAM of an environment (state.PRNGKey after a random reset, the GymWrapper's reference
+# generator) advances through the same split() tree as the reference's. All functions are vectorised over a leading batch
+# of keys [..., 2] (the reference vmaps the same scalar code over the batch).
+def _u32(x):
+    return x & _M32
+
+
+def randint(key: torch.Tensor, n: int, minval: int, maxval: int) -> torch.Tensor:
+    """jax.random.randint(key, (n,), minval, maxval) with the default int32 dtype for every key of a [..., 2] batch ->
+    int64 tensor [..., n]. Two 32-bit draws (higher / lower bits from split(key)) reduce the modulo bias; all arithmetic is
+    uint32 with wrap-around, as in the source."""
+    minval, maxval = int(minval), int(maxval)
+    ks = split(key)
+    higher, lower = random_bits(ks[..., 0, :], n, 32), random_bits(ks[..., 1, :], n, 32)
+    span = (maxval - minval) & _M32
+    if maxval <= minval:
+        span = 1
+    multiplier = (1 << 16) % span
+    multiplier = ((multiplier * multiplier) & _M32) % span
+    off = _u32(_u32((higher % span) * multiplier) + (lower % span)) % span
+    return off + minval
+
+
+def _uniform_scalar(key, dtype, minval=0.0, maxval=1.0):
+    return uniform(key, 1, dtype, minval, maxval)[..., 0]
+
+
+def normal(key: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    """jax.random.normal(key, (), dtype): sqrt(2) * erf_inv(uniform(key, (), minval=nextafter(-1, 0), maxval=1))."""
+    lo = torch.nextafter(torch.tensor(-1.0, dtype=dtype), torch.tensor(0.0, dtype=dtype)).item()
+    u = _uniform_scalar(key, dtype, lo, 1.0)
+    return torch.erfinv(u) * torch.tensor(2.0, dtype=dtype).sqrt().to(u.device)
+
+
+def exponential(key: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    """jax.random.exponential(key, (), dtype): -log1p(-uniform(key))."""
+    return -torch.log1p(-_uniform_scalar(key, dtype))
+
+
+def rademacher(key: torch.Tensor, n: int, dtype=torch.float32) -> torch.Tensor:
+    """jax.random.rademacher(key, (n,), dtype): 2 * bernoulli(key, 0.5, (n,)) - 1, bernoulli = uniform(key, (n,)) < p."""
+    return (uniform(key, n, dtype) < 0.5).to(dtype) * 2 - 1
+
+
+def _gamma_one(key: torch.Tensor, alpha: float, dtype) -> torch.Tensor:
+    """random._gamma_one (Marsaglia & Tsang, with the alpha < 1 boost) for a batch of keys [M, 2], scalar alpha. The two
+    nested lax.while_loops of the source become masked iterations: a lane keeps its values once its own loop has ended."""
+    dev = key.device
+    t = lambda v: torch.tensor(v, dtype=dtype, device=dev)
+    one, third = t(1.0), t(1.0 / 3.0)
+    boost_mask = alpha >= 1.0
+    a = t(alpha) if boost_mask else t(alpha) + one
+    d = a - third
+    c = third / torch.sqrt(d)
+    sp = split(key)
+    k, subkey = sp[:, 0, :], sp[:, 1, :]
+    M = key.shape[0]
+    X, V, U = torch.zeros(M, dtype=dtype, device=dev), torch.ones(M, dtype=dtype, device=dev), torch.full((M,), 2.0, dtype=dtype, device=dev)
+    active = torch.ones(M, dtype=torch.bool, device=dev)
+    for _ in range(200):  # P(reject) per round is a few percent; 200 rounds never bind in practice
+        if not bool(active.any()):
+            break
+        s3 = split(k, 3)
+        k_next, kk, u_key = s3[:, 0, :], s3[:, 1, :], s3[:, 2, :]
+        x, v = torch.zeros(M, dtype=dtype, device=dev), torch.full((M,), -1.0, dtype=dtype, device=dev)
+        inner = active.clone()
+        for _ in range(200):
+            if not bool(inner.any()):
+                break
+            s2 = split(kk)
+            xn = normal(s2[:, 1, :], dtype)
+            vn = one + xn * c
+            kk = torch.where(inner[:, None], s2[:, 0, :], kk)
+            x, v = torch.where(inner, xn, x), torch.where(inner, vn, v)
+            inner = inner & (v <= 0)
+        Xn, Vn, Un = x * x, v * v * v, _uniform_scalar(u_key, dtype)
+        k = torch.where(active[:, None], k_next, k)
+        X, V, U = torch.where(active, Xn, X), torch.where(active, Vn, V), torch.where(active, Un, U)
+        cond = (U >= one - t(0.0331) * (X * X)) & (torch.log(U) >= X * t(0.5) + d * ((one - V) + torch.log(V)))
+        active = active & cond
+    samples = one - _uniform_scalar(subkey, dtype)
+    boost = torch.ones(M, dtype=dtype, device=dev) if boost_mask else torch.pow(samples, one / t(alpha))
+    return d * V * boost
+
+
+def gamma(key: torch.Tensor, alpha: float, n: int, dtype=torch.float32) -> torch.Tensor:
+    """jax.random.gamma(key, alpha, (n,), dtype): one sub-key per sample (split(key, n)), each through _gamma_one."""
+    key = torch.as_tensor(key).to(torch.int64)
+    lead = key.shape[:-1]
+    keys = split(key, n).reshape(-1, 2)
+    return _gamma_one(keys, float(alpha), dtype).reshape(tuple(lead) + (n,))
+
+
+def generalized_normal(key: torch.Tensor, p: float, n: int, dtype=torch.float32) -> torch.Tensor:
+    """jax.random.generalized_normal(key, p, (n,), dtype): rademacher * gamma(1/p) ** (1/p) from split(key)."""
+    ks = split(key)
+    g = gamma(ks[..., 0, :], 1.0 / p, n, dtype)
+    r = rademacher(ks[..., 1, :], n, dtype)
+    return r * torch.pow(g, torch.tensor(1.0 / p, dtype=dtype, device=g.device))
+
+
+def ball(key: torch.Tensor, d: int, p: float = 2, dtype=torch.float32) -> torch.Tensor:
+    """jax.random.ball(key, d, p, (), dtype): a point uniform in the unit p-ball, [..., d] for a [..., 2] batch of keys
+    (the PMSM random current draw, pmsm_env.py:405-406)."""
+    ks = split(key)
+    g = generalized_normal(ks[..., 0, :], p, d, dtype)
+    e = exponential(ks[..., 1, :], dtype)
+    inv_p = torch.tensor(1.0 / p, dtype=dtype, device=g.device)
+    return g / torch.pow(torch.pow(g.abs(), torch.tensor(float(p), dtype=dtype, device=g.device)).sum(-1) + e, inv_p)[..., None]
