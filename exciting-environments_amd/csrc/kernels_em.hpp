@@ -14,8 +14,15 @@ namespace excenv {
 constexpr int EM_TK = EXCENV_EM_TK;  // solver steps staged per tile
 constexpr int EM_LANES = 64;  // one wave per workgroup
 
+// Leading dimension of the observation tile: rows of TK*OW words + a pad that keeps 16-byte row alignment when OW is a
+// multiple of the 16-byte vector width (then ds_write_b128 / ds_read_b128 are conflict-free: consecutive lanes / rows sit
+// 4 banks apart modulo 32), else one word (odd stride for the scalar accesses).
+template <typename T> __host__ __device__ constexpr int em_ldo(int OW) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  return (OW % VW) == 0 ? EM_TK * OW + VW : ((EM_TK * OW) | 1);
+}
 template <typename T> __host__ __device__ constexpr size_t em_lds_elems(int A, int OW, int S, bool with_states) {
-  return (size_t)EM_LANES * ((EM_TK + 1) * A + 1) + (size_t)EM_LANES * (EM_TK * OW + 1) +
+  return (size_t)EM_LANES * ((EM_TK + 1) * A + 1) + (size_t)EM_LANES * em_ldo<T>(OW) +
          (with_states ? (size_t)S * EM_LANES * (EM_TK + 1) : 0);
 }
 
@@ -42,7 +49,10 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
   extern __shared__ __align__(16) unsigned char excenv_em_smem[];
   const int OW = O + ka.n_control;
   const bool with_states = ka.straj[0] != nullptr;
-  const int LDA = (TK + 1) * A + 1, LDO = TK * OW + 1, LDS_ = TK + 1;  // odd leading dimensions: conflict-free columns
+  constexpr int VW = 16 / (int)sizeof(T);  // elements per 16-byte piece
+  static_assert((TK & (TK - 1)) == 0 && EM_LANES % TK == 0, "EXCENV_EM_TK must be a power of two <= 64");
+  const bool vec_rows = (OW % VW) == 0;  // every env row, tile start and LDS row is then 16-byte aligned
+  const int LDA = (TK + 1) * A + 1, LDO = em_ldo<T>(OW), LDS_ = TK + 1;  // odd leading dimensions: conflict-free columns
   T* tact = reinterpret_cast<T*>(excenv_em_smem);
   T* tobs = tact + EM_LANES * LDA;
   T* tst = tobs + EM_LANES * LDO;
@@ -139,8 +149,23 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
       }
       T ob[O];
       M::observe(sv, c, ob);
+      if constexpr (O % VW == 0) {
+        if (vec_rows) {  // 16-byte LDS stores (row base and t * OW are multiples of VW)
 #pragma unroll
-      for (int q = 0; q < O; ++q) tobs[lane * LDO + t * OW + q] = ob[q];
+          for (int q = 0; q < O; q += VW) {
+            T v[VW];
+#pragma unroll
+            for (int h = 0; h < VW; ++h) v[h] = ob[q + h];
+            store_v<T, VW>(&tobs[lane * LDO + t * OW + q], v);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < O; ++q) tobs[lane * LDO + t * OW + q] = ob[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < O; ++q) tobs[lane * LDO + t * OW + q] = ob[q];
+      }
 #pragma unroll
       for (int j = 0; j < EXCENV_MAX_CONTROL; ++j)
         if (j < ka.n_control) tobs[lane * LDO + t * OW + O + j] = cref[j];
@@ -165,28 +190,68 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
       }
     }
     __syncthreads();
+    // The next action tile is parked BEFORE the flush: its loads were issued a whole tile ago, so the s_waitcnt in front of
+    // these LDS writes is already satisfied — and it must not come after the flush, where the in-order vmcnt would make it
+    // wait for every trajectory store of this tile (a full memory drain per tile). This tile's steps are done with tact
+    // (barrier above) and the flush below reads only tobs / tst; the barrier at the loop top publishes the new tile.
+    park_actions(n0 + TK);
     // ---- flush: per-env contiguous runs ----
+    // Full tiles take the batched paths: all LDS reads of a batch are issued before the first global store, so the wave
+    // pays one LDS round trip per batch instead of one per word (the trip counts are static, nothing is loop-carried).
     {
       const int per = cnt * OW;
       T* dst = ka.obs + (b0 * (N + 1) + n0) * OW;
-      constexpr int VW = 16 / (int)sizeof(T);  // elements per 16-byte piece
-      if ((OW % VW) == 0) {  // every env row and tile start is then 16-byte aligned
+      if (vec_rows && cnt == TK) {
+        const int CH = per / VW;  // 16-byte pieces per env; the wave walks 64 * CH pieces in CH rounds
+        EmWalk w(lane, CH);
+        for (int it0 = 0; it0 < CH; it0 += 4) {
+          T v[4][VW];
+          int es[4], js[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            es[u] = w.e;
+            js[u] = w.j * VW;
+            const int er = (w.e < EM_LANES) ? w.e : EM_LANES - 1;  // rounds past CH stay inside the tile (masked below)
+            load_v<T, VW>(&tobs[er * LDO + js[u]], v[u]);
+            w.next();
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (it0 + u < CH && es[u] < nenv) store_v<T, VW>(dst + (int64_t)es[u] * (N + 1) * OW + js[u], v[u]);
+        }
+      } else if (vec_rows) {
         for (EmWalk w(lane, per / VW); w.e < nenv; w.next()) {
           const int j = w.j * VW;
           T v[VW];
-#pragma unroll
-          for (int q = 0; q < VW; ++q) v[q] = tobs[w.e * LDO + j + q];
+          load_v<T, VW>(&tobs[w.e * LDO + j], v);
           store_v<T, VW>(dst + (int64_t)w.e * (N + 1) * OW + j, v);
         }
       } else {
         for (EmWalk w(lane, per); w.e < nenv; w.next()) dst[(int64_t)w.e * (N + 1) * OW + w.j] = tobs[w.e * LDO + w.j];
       }
       if (with_states) {
-        const EmWalk w0(lane, cnt);
+        if (cnt == TK) {  // lane -> (env e0 + it * 64/TK, step j): TK rounds per leaf, all reads of a leaf in flight together
+          constexpr int EPR = EM_LANES / TK;  // envs covered per round
+          const int e0 = lane / TK, j = lane % TK;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-          T* sd = ka.straj[s] + b0 * (N + 1) + n0;
-          for (EmWalk w = w0; w.e < nenv; w.next()) sd[(int64_t)w.e * (N + 1) + w.j] = tst[(s * EM_LANES + w.e) * LDS_ + w.j];
+          for (int s = 0; s < S; ++s) {
+            T v[TK];
+#pragma unroll
+            for (int it = 0; it < TK; ++it) v[it] = tst[(s * EM_LANES + e0 + it * EPR) * LDS_ + j];
+            T* sd = ka.straj[s] + b0 * (N + 1) + n0 + j;
+#pragma unroll
+            for (int it = 0; it < TK; ++it) {
+              const int e = e0 + it * EPR;
+              if (e < nenv) sd[(int64_t)e * (N + 1)] = v[it];
+            }
+          }
+        } else {
+          const EmWalk w0(lane, cnt);
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            T* sd = ka.straj[s] + b0 * (N + 1) + n0;
+            for (EmWalk w = w0; w.e < nenv; w.next()) sd[(int64_t)w.e * (N + 1) + w.j] = tst[(s * EM_LANES + w.e) * LDS_ + w.j];
+          }
         }
       }
     }
@@ -196,7 +261,6 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
         for (int j = 0; j < S; ++j) ka.last_state[j][i0] = sv[j];
       }
     }
-    park_actions(n0 + TK);  // this tile's steps are done with tact (barrier above), the next barrier publishes it
   }
 }
 

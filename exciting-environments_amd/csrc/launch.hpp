@@ -57,7 +57,8 @@ struct SimCall {
 static inline bool em_fused_eligible(int em_mode, int action_layout, int traj_layout, int32_t substeps, bool with_gym,
                                      int A, int OW, int S, bool with_states, size_t elem) {
   return em_mode != 1 && action_layout == EXCENV_LAYOUT_ENV_MAJOR && traj_layout == EXCENV_LAYOUT_ENV_MAJOR &&
-         substeps == 1 && !with_gym && em_lds_elems<float>(A, OW, S, with_states) * elem <= 150 * 1024;
+         substeps == 1 && !with_gym &&
+         (elem == 8 ? em_lds_elems<double>(A, OW, S, with_states) : em_lds_elems<float>(A, OW, S, with_states)) * elem <= 150 * 1024;
 }
 
 struct TrajGymCall {
