@@ -6,17 +6,17 @@ import torch
 
 import oracle
 from helpers import NP_DTYPE, random_state, spec_of, to_state
-from helpers_lut import linear_lut, saturating_lut
+from helpers_lut import linear_lut, saturating_lut, sew_shaped_lut
 
 pytestmark = pytest.mark.gpu
 
 
-def _make(B, dtype, solver, lut, control_state=None):
+def _make(B, dtype, solver, lut, control_state=None, variant="BRUSA"):
     import exciting_environments_amd as ex
     from exciting_environments_amd import EnvironmentRegistry, MotorVariant, prepare_pmsm_lut
 
     solv = {"euler": ex.Euler(), "rk4": ex.RK4(), "tsit5": ex.Tsit5()}[solver]
-    env = EnvironmentRegistry.PMSM.make(batch_size=B, saturated=True, motor_variant=MotorVariant.BRUSA, pmsm_lut=lut, solver=solv,
+    env = EnvironmentRegistry.PMSM.make(batch_size=B, saturated=True, motor_variant=MotorVariant[variant], pmsm_lut=lut, solver=solv,
                                         dtype=dtype, device="cuda", control_state=control_state)
     ep = env.env_properties
     params = {n: getattr(ep.static_params, n) for n in env.PARAM_FIELDS}
@@ -120,3 +120,35 @@ def test_non_uniform_grid_takes_the_exact_search_path():
     obs, new = env.vmap_step(to_state(env, st), torch.as_tensor(act, device=env.device))
     o_ref, s_ref = oracle.step("pmsm", "euler", st, act, props, spec["tau"])
     assert np.allclose(obs.cpu().numpy(), o_ref, rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_sew_shaped_tables_with_circular_nan_region(dtype):
+    """The grid and NaN geometry of the reference's SEW file (33 x 18 tables, i_d in [-16, 1] A, everything outside the
+    current-limit circle NaN; values synthetic): prepare_pmsm_lut -> (20, 35) padded grids staged in LDS, kernels vs the
+    oracle on states inside the circle, on its rim (cells whose corners were NaN-filled) and far outside (constant
+    extrapolation), step and both trajectory semantics. fp32 is held to a short horizon and a looser bound: with the SEW
+    voltage range (+-367 V) against ~2 mH one Euler step moves the currents by more than the table's whole range, so fp32
+    rounding of the voltage path alone separates fp32 from fp64 by 2e-5 after one step and 5e-4 after eight (measured with
+    the oracle); fp64 keeps the strict bound over 40 steps."""
+    B, K = 2048, (40 if dtype == torch.float64 else 3)
+    env, props, keep, spec = _make(B, dtype, "euler", sew_shaped_lut(), variant="SEW")
+    npdt = NP_DTYPE[dtype]
+    rng = np.random.default_rng(441)
+    ang, rad = rng.uniform(0, 2 * np.pi, B), np.concatenate([rng.uniform(0, 14, B // 2), rng.uniform(14, 17, B // 4), rng.uniform(17, 40, B - B // 2 - B // 4)])
+    st = [np.zeros(B, npdt), np.zeros(B, npdt), rng.uniform(-3, 3, B).astype(npdt), (-np.abs(rad * np.cos(ang))).astype(npdt),
+          (rad * np.sin(ang)).astype(npdt), np.zeros(B, npdt), rng.uniform(0, 300, B).astype(npdt)]
+    acts = rng.uniform(-1, 1, (B, K, 2)).astype(npdt)
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+    obs, new = env.vmap_step(to_state(env, st), torch.as_tensor(acts[:, 0], device=env.device))
+    o_ref, s_ref = oracle.step("pmsm", "euler", st, acts[:, 0], props, spec["tau"])
+    assert np.isfinite(o_ref).all() and np.allclose(obs.cpu().numpy(), o_ref, rtol=tol, atol=tol)
+    for sem, osem in (("step", oracle.SEM_STEP), ("ahead", oracle.SEM_AHEAD)):
+        env.sim_ahead_semantics = sem
+        for layout in ("lane_major", "env_major"):
+            env.traj_layout = layout
+            o, s, l = env.vmap_sim_ahead(to_state(env, st), torch.as_tensor(acts, device=env.device), env.tau, env.tau)
+            o_ref, s_ref, l_ref = oracle.sim_ahead("pmsm", "euler", st, acts, props, spec["tau"], semantics=osem)
+            ok = np.isfinite(o_ref).all(axis=(1, 2))
+            assert ok.mean() > 0.9
+            assert np.allclose(o.cpu().numpy()[ok], o_ref[ok], rtol=tol, atol=tol), (sem, layout)

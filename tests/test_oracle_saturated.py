@@ -70,3 +70,50 @@ def test_saturating_lut_differs_and_extrapolates_constant():
     psi_d_edge, psi_q_edge = tab[0, -1, 4], tab[0, -1, 5]
     want = 1.5 * 3 * (psi_d_edge * 300.0 - psi_q_edge * np.array([-1e4, -2e4]))
     assert np.allclose(s1[5], want, rtol=1e-12)
+
+
+def test_prepare_lut_on_the_sew_grid_with_its_circular_nan_region():
+    """The reference's SEW tables are (33, 18) with everything outside the current-limit circle NaN (142 / 188 of 594
+    entries): nearest-neighbour fill + edge padding must leave no NaN, keep every valid node and produce the extended grids."""
+    from helpers_lut import sew_shaped_lut
+
+    lut = sew_shaped_lut()
+    n_nan = {q: int(np.isnan(lut[q]).sum()) for q in ("Psi_d", "L_dd")}
+    assert n_nan["Psi_d"] > 100 and n_nan["L_dd"] > n_nan["Psi_d"]
+    raw = {q: np.array(lut[q]) for q in ("Psi_d", "L_qq")}
+    gd, gq, tab = prepare_pmsm_lut(lut)
+    assert gd.shape == (20,) and gq.shape == (35,) and tab.shape == (20, 35, 8) and not np.isnan(tab).any()
+    assert np.allclose(gd, np.linspace(-17.0, 2.0, 20)) and np.allclose(gq, np.linspace(-17.0, 17.0, 35))
+    for k, q in ((4, "Psi_d"), (3, "L_qq")):
+        inner = tab[1:-1, 1:-1, k].T  # (33, 18) like the file
+        valid = ~np.isnan(raw[q])
+        assert np.array_equal(inner[valid], raw[q][valid])
+        assert inner[~valid].min() >= raw[q][valid].min() and inner[~valid].max() <= raw[q][valid].max()  # filled from valid nodes
+    # the oracle runs on it: a point inside the circle interpolates between valid nodes, one far outside extrapolates constantly
+    B = 4
+    pn = {"u_d_buffer": (-366.0, 366.0), "u_q_buffer": (-366.0, 366.0), "epsilon": (-np.pi, np.pi), "i_d": (-16.0, 0.0),
+          "i_q": (-16.0, 16.0), "torque": (-15.0, 15.0), "omega_el": (0.0, 837.0)}
+    an = {"u_d": (-366.0, 366.0), "u_q": (-366.0, 366.0)}
+    params = dict(p=4, r_s=208e-3, l_d=float("nan"), l_q=float("nan"), psi_p=float("nan"), u_dc=550, deadtime=1)
+    props, keep = oracle.make_props("pmsm", params, pn, an, np.float64, B, pmsm_lut=(gd, gq, tab))
+    st = [np.zeros(B), np.zeros(B), np.zeros(B), np.array([-3.0, -15.9, -40.0, 0.9]), np.array([2.0, 0.1, 30.0, -15.9]),
+          np.zeros(B), np.full(B, 50.0)]
+    obs, new = oracle.step("pmsm", "euler", st, np.zeros((B, 2)), props, 1e-4)
+    assert np.isfinite(obs).all() and all(np.isfinite(x).all() for x in new)
+
+
+@pytest.mark.skipif(not __import__("os").path.exists("/root/reference/exciting_environments/pmsm/LUT_SEW_jax_grad.mat"),
+                    reason="the reference's motor data files exist only in the build container (they are not redistributed)")
+@pytest.mark.parametrize("motor,shape", [("BRUSA", (28, 53, 8)), ("SEW", (20, 35, 8))])
+def test_prepare_lut_on_the_reference_motor_files(motor, shape):
+    """In the build container only: the reference's own LUT files (read as data) go through prepare_pmsm_lut and the oracle."""
+    from scipy.io import loadmat
+
+    lut = loadmat(f"/root/reference/exciting_environments/pmsm/LUT_{motor}_jax_grad.mat")
+    raw = np.array(lut["Psi_q"])
+    gd, gq, tab = prepare_pmsm_lut(lut)
+    assert tab.shape == shape and not np.isnan(tab).any() and np.all(np.diff(gd) > 0) and np.all(np.diff(gq) > 0)
+    valid = ~np.isnan(raw)
+    assert np.array_equal(tab[1:-1, 1:-1, 5].T[valid], raw[valid])
+    det = tab[..., 0] * tab[..., 3] - tab[..., 1] * tab[..., 2]
+    assert (det > 0).all()  # the inductance matrix stays invertible at every (filled / padded) node

@@ -8,6 +8,8 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# the un-profiled bench line of the same session (same box, same minute) — bench.py's own --steps / --warmup defaults
+python3 "$REPO/bench.py" --no-cpu-baseline "$@" > "$OUT/bench.json" 2> "$OUT/bench.err" || echo "bench run failed"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 20 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err" || echo "trace run failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/tools/traffic_probe.py" "$@" > "$OUT/pmc_fetch.log" 2>&1 || echo "pmc fetch run failed"

@@ -18,6 +18,35 @@ def find(sub, pat):
 
 
 lines = [f"# rocprofv3 summary {tag}", ""]
+# ---- the un-profiled bench line of the SAME gpurun session + the roofline fraction recomputed from the profile ---------
+bench = None
+bpath = os.path.join(src, "bench.json")
+if os.path.exists(bpath):
+    try:
+        bench = json.loads([l for l in open(bpath).read().splitlines() if l.startswith("{")][-1])
+    except Exception:
+        bench = None
+hot_avg_ms = None
+for f in find("trace", "*kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        if "sim_ahead" in r.get("Name", "") or "step_kernel" in r.get("Name", ""):
+            avg = float(r.get("AverageNs", 0) or 0) / 1e6
+            if hot_avg_ms is None or float(r.get("TotalDurationNs", 0) or 0) > hot_avg_ms[1]:
+                hot_avg_ms = (avg, float(r.get("TotalDurationNs", 0) or 0), r.get("Name", ""), r.get("Calls"))
+if bench is not None:
+    rf = bench["roofline"]
+    lines += ["## same-session bench line (un-profiled run of `bench.py`, HIP events) and the fraction recomputed from this profile", "",
+              f"* workload: {bench['config']['workload']}",
+              f"* bench line: value {bench['value']:.4e} {bench['unit']}, ms_per_step {bench['ms_per_step']:.4f}, "
+              f"kernel_ms (HIP events) {rf['kernel_ms']:.4f}, roofline.frac {rf['frac']:.4f}",
+              f"* algorithmic bytes per launch: {rf['algorithmic_bytes_per_env_step']} B x {bench['config']['batch_per_gpu']} envs x "
+              f"{bench['config']['chunk_steps']} steps = {rf['algorithmic_bytes_per_launch']:.4e} B"]
+    if hot_avg_ms is not None:
+        gbs = rf["algorithmic_bytes_per_launch"] / (hot_avg_ms[0] * 1e-3) / 1e9
+        lines += [f"* rocprofv3 --kernel-trace --stats average of the dominant kernel ({hot_avg_ms[3]} calls, profiled run): "
+                  f"{hot_avg_ms[0]:.4f} ms -> {gbs:.0f} GB/s algorithmic = **{gbs / 8000.0:.4f} of the 8 TB/s HBM peak** "
+                  f"(bench line, un-profiled: {rf['frac']:.4f}; profiled passes run at a slightly lower clock, MI355X_MICROARCH.md DVFS item 2)"]
+    lines.append("")
 # ---- kernel stats ------------------------------------------------------------------------------
 for f in find("trace", "*kernel_stats.csv"):
     lines += [f"## kernel-trace --stats ({os.path.basename(f)})", "", "| kernel | calls | total ms | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|---|"]
@@ -32,7 +61,7 @@ for f in find("trace", "*kernel_trace.csv"):
     seen = {}
     for r in csv.DictReader(open(f)):
         n = r.get("Kernel_Name", "")
-        if "sim_ahead_kernel" in n or "step_kernel" in n:
+        if "sim_ahead" in n or "step_kernel" in n:
             seen[n] = r
     if seen:
         lines += ["## dispatch resources (kernel_trace.csv)", "", "| kernel | VGPR | accum VGPR | SGPR | LDS | scratch | workgroup | grid |", "|---|---|---|---|---|---|---|---|"]
@@ -62,7 +91,7 @@ if any(pmc.values()):
         if not (fz + wz >= 1000 or "sim_ahead" in k or "step_kernel" in k):
             continue
         lines.append(f"| `{k[:100]}` | {max(n1, n2)} | {fz:.0f} | {wz:.0f} |")
-        if "sim_ahead_kernel" in k or "step_kernel" in k:
+        if "sim_ahead" in k or "step_kernel" in k:
             hot = (fz, wz, k)
         if "trunc" in k.lower():
             calib = (fz, wz)
@@ -94,7 +123,7 @@ for sub in ("pmc_sq", "pmc_sq2"):
     for f in find(sub, "*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k = r.get("Kernel_Name", "")
-            if "sim_ahead_kernel" in k or "step_kernel" in k:
+            if "sim_ahead" in k or "step_kernel" in k:
                 sq[k][r.get("Counter_Name")] += float(r.get("Counter_Value", 0) or 0)
                 nd[(k, r.get("Counter_Name"))].add(r.get("Dispatch_Id"))
 if sq:
