@@ -306,4 +306,18 @@ int excenv_probe_math(int which, int dtype, int64_t n, const void* in, void* out
   return check_launch("excenv_probe_math");
 }
 
+int excenv_probe_div(int dtype, int64_t n, const void* num, const void* den, void* out_fast, void* out_ref, void* stream) {
+  if (n < 0 || (dtype != EXCENV_F32 && dtype != EXCENV_F64)) { set_error("excenv_probe_div: bad argument"); return EXCENV_EINVAL; }
+  if (!num || !den || !out_fast || !out_ref) { set_error("excenv_probe_div: NULL argument"); return EXCENV_ENULL; }
+  if (n == 0) return EXCENV_OK;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (dtype == EXCENV_F32)
+    hipLaunchKernelGGL((probe_div_kernel<float>), grid, block, 0, (hipStream_t)stream, n, (const float*)num, (const float*)den,
+                       (float*)out_fast, (float*)out_ref);
+  else
+    hipLaunchKernelGGL((probe_div_kernel<double>), grid, block, 0, (hipStream_t)stream, n, (const double*)num,
+                       (const double*)den, (double*)out_fast, (double*)out_ref);
+  return check_launch("excenv_probe_div");
+}
+
 }  // extern "C"

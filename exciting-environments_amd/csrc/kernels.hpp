@@ -103,6 +103,7 @@ __device__ __forceinline__ void load_ctx(Ctx<T, M>& c, const KProps<T, M>& kp, i
   c.lut_nd = kp.lut_nd;
   c.lut_nq = kp.lut_nq;
   c.lut_lds = 0;
+  prep_ctx(c);
 }
 
 // PMSM saturated model: copy the grids and the node-interleaved tables into LDS once per workgroup (47 KB in fp32 —
@@ -625,6 +626,16 @@ template <typename T> __global__ void probe_kernel(int which, int64_t n, const T
   else if (which == 1) r = cos_t(x);
   else r = wrap_angle(x);
   out[i] = r;
+}
+
+// out_fast[i] = InvDiv(den[i]).div(num[i]), out_ref[i] = num[i] / den[i] (the compiler's IEEE sequence) — must be equal bits
+template <typename T> __global__ void probe_div_kernel(int64_t n, const T* num, const T* den, T* out_fast, T* out_ref) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  InvDiv<T> d;
+  d.init(den[i]);
+  out_fast[i] = d.div(num[i]);
+  out_ref[i] = num[i] / den[i];
 }
 
 }  // namespace excenv

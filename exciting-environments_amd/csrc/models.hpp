@@ -20,54 +20,74 @@ template <typename T, class M> struct Ctx {
   const T* lut_tab;
   int lut_nd, lut_nq;
   int lut_lds;  // tables + grids staged in dynamic LDS (layout: tables, grid_d, grid_q)
+  // loop-invariant denominators (devmath.hpp InvDiv): (smax - smin) of every state field (normalisation) and the model's own
+  InvDiv<T> nrm[M::S];
+  InvDiv<T> den[M::ND > 0 ? M::ND : 1];
 };
+
+// utils.py:13-17 with the state field's precomputed (smax - smin): same operation order, same bits as normalize()
+template <typename T, class M> __device__ __forceinline__ T normalize_field(const Ctx<T, M>& c, int j, T x) {
+  return c.nrm[j].div(T(2) * (x - c.smin[j])) - T(1);
+}
+
+template <typename T, class M> __device__ __forceinline__ void prep_ctx(Ctx<T, M>& c) {
+#pragma unroll
+  for (int j = 0; j < M::S; ++j) c.nrm[j].init(c.smax[j] - c.smin[j]);
+  M::prep(c);
+}
 
 // ---- Pendulum: pendulum_env.py:144-150,188 ; P = (g,l,m) --------------------------------
 template <typename T> struct Pendulum {
-  static constexpr int ID = EXCENV_PENDULUM, S = 2, A = 1, O = 2, P = 3, NY = 2;
+  static constexpr int ID = EXCENV_PENDULUM, S = 2, A = 1, O = 2, P = 3, NY = 2, ND = 1;
   static constexpr bool IS_PMSM = false;
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, Pendulum>;
+  __device__ static __forceinline__ void prep(C& c) { c.den[0].init(c.P[2] * (c.P[1] * c.P[1])); }  // m * (l * l)
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; y[1] = st[1]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; st[1] = y[1]; }
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
     const T g = c.P[0], l = c.P[1], m = c.P[2];
-    dy[1] = (u[0] + l * m * g * sin_t(y[0])) / (m * (l * l));
+    dy[1] = c.den[0].div(u[0] + l * m * g * sin_t(y[0]));  // / (m * (l * l))
     dy[0] = y[1];
   }
   __device__ static __forceinline__ void post(T (&st)[S], const C&) { st[0] = wrap_angle(st[0]); }
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
-    ob[0] = normalize(st[0], c.smin[0], c.smax[0]);
-    ob[1] = normalize(st[1], c.smin[1], c.smax[1]);
+    ob[0] = normalize_field(c, 0, st[0]);
+    ob[1] = normalize_field(c, 1, st[1]);
   }
 };
 
 // ---- MassSpringDamper: mass_spring_damper_env.py:142-148 ; P = (d,k,m) ---------------------
 template <typename T> struct MassSpringDamper {
-  static constexpr int ID = EXCENV_MASS_SPRING_DAMPER, S = 2, A = 1, O = 2, P = 3, NY = 2;
+  static constexpr int ID = EXCENV_MASS_SPRING_DAMPER, S = 2, A = 1, O = 2, P = 3, NY = 2, ND = 1;
   static constexpr bool IS_PMSM = false;
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, MassSpringDamper>;
+  __device__ static __forceinline__ void prep(C& c) { c.den[0].init(c.P[2]); }  // m
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; y[1] = st[1]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; st[1] = y[1]; }
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
-    const T d = c.P[0], k = c.P[1], m = c.P[2];
-    dy[1] = (u[0] - d * y[1] - k * y[0]) / m;
+    const T d = c.P[0], k = c.P[1];
+    dy[1] = c.den[0].div(u[0] - d * y[1] - k * y[0]);  // / m
     dy[0] = y[1];
   }
   __device__ static __forceinline__ void post(T (&)[S], const C&) {}
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
-    ob[0] = normalize(st[0], c.smin[0], c.smax[0]);
-    ob[1] = normalize(st[1], c.smin[1], c.smax[1]);
+    ob[0] = normalize_field(c, 0, st[0]);
+    ob[1] = normalize_field(c, 1, st[1]);
   }
 };
 
 // ---- CartPole: cart_pole_env.py:159-180,229 ; P = (mu_p,mu_c,l,m_p,m_c,g) -----------------
 template <typename T> struct CartPole {
-  static constexpr int ID = EXCENV_CART_POLE, S = 4, A = 1, O = 4, P = 6, NY = 4;
+  static constexpr int ID = EXCENV_CART_POLE, S = 4, A = 1, O = 4, P = 6, NY = 4, ND = 2;
   static constexpr bool IS_PMSM = false;
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, CartPole>;
+  __device__ static __forceinline__ void prep(C& c) {
+    c.den[0].init(c.P[4] + c.P[3]);  // m_c + m_p
+    c.den[1].init(c.P[3] * c.P[2]);  // m_p * l
+  }
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) y[j] = st[j];
@@ -77,16 +97,16 @@ template <typename T> struct CartPole {
     for (int j = 0; j < 4; ++j) st[j] = y[j];
   }
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
-    const T mu_p = c.P[0], mu_c = c.P[1], l = c.P[2], m_p = c.P[3], m_c = c.P[4], g = c.P[5];
+    const T mu_p = c.P[0], mu_c = c.P[1], l = c.P[2], m_p = c.P[3], g = c.P[5];
     const T velocity = y[1], theta = y[2], omega = y[3];
     T s, co;
     sincos_t(theta, s, co);
+    const auto& by_mass = c.den[0];  // / (m_c + m_p)
     const T d_omega =
-        (g * s + co * ((-u[0] - m_p * l * (omega * omega) * s + mu_c * sign_of(velocity)) / (m_c + m_p)) -
-         (mu_p * omega) / (m_p * l)) /
-        (l * (T(4.0 / 3.0) - (m_p * (co * co)) / (m_c + m_p)));
-    const T d_velocity =
-        (u[0] + m_p * l * ((omega * omega) * s - d_omega * co) - mu_c * sign_of(velocity)) / (m_c + m_p);
+        (g * s + co * by_mass.div(-u[0] - m_p * l * (omega * omega) * s + mu_c * sign_of(velocity)) -
+         c.den[1].div(mu_p * omega)) /
+        (l * (T(4.0 / 3.0) - by_mass.div(m_p * (co * co))));
+    const T d_velocity = by_mass.div(u[0] + m_p * l * ((omega * omega) * s - d_omega * co) - mu_c * sign_of(velocity));
     dy[0] = velocity;
     dy[1] = d_velocity;
     dy[2] = omega;
@@ -95,16 +115,17 @@ template <typename T> struct CartPole {
   __device__ static __forceinline__ void post(T (&st)[S], const C&) { st[2] = wrap_angle(st[2]); }
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ob[j] = normalize(st[j], c.smin[j], c.smax[j]);
+    for (int j = 0; j < 4; ++j) ob[j] = normalize_field(c, j, st[j]);
   }
 };
 
 // ---- Acrobot: acrobot_env.py:171-197,247-248 ; P = (g,l_1,l_2,m_1,m_2,l_c1,l_c2,I_1,I_2) ----
 template <typename T> struct Acrobot {
-  static constexpr int ID = EXCENV_ACROBOT, S = 4, A = 1, O = 4, P = 9, NY = 4;
+  static constexpr int ID = EXCENV_ACROBOT, S = 4, A = 1, O = 4, P = 9, NY = 4, ND = 0;
   static constexpr bool IS_PMSM = false;
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, Acrobot>;
+  __device__ static __forceinline__ void prep(C&) {}  // every denominator of the vector field depends on theta_2
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) y[j] = st[j];
@@ -140,43 +161,48 @@ template <typename T> struct Acrobot {
   }
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ob[j] = normalize(st[j], c.smin[j], c.smax[j]);
+    for (int j = 0; j < 4; ++j) ob[j] = normalize_field(c, j, st[j]);
   }
 };
 
 // ---- FluidTank: fluid_tank_env.py:97-106,146 ; P = (base_area, orifice_area, c_d, g) ---------
 template <typename T> struct FluidTank {
-  static constexpr int ID = EXCENV_FLUID_TANK, S = 1, A = 1, O = 1, P = 4, NY = 1;
+  static constexpr int ID = EXCENV_FLUID_TANK, S = 1, A = 1, O = 1, P = 4, NY = 1, ND = 1;
   static constexpr bool IS_PMSM = false;
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, FluidTank>;
+  __device__ static __forceinline__ void prep(C& c) { c.den[0].init(c.P[0]); }  // base_area
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; }
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
     const T base_area = c.P[0], orifice_area = c.P[1], c_d = c.P[2], g = c.P[3];
     const T h = max_nan(y[0], T(0));
-    dy[0] = u[0] / base_area - c_d * orifice_area / base_area * xsqrt(T(2) * g * h);
+    dy[0] = c.den[0].div(u[0]) - c_d * orifice_area / base_area * xsqrt(T(2) * g * h);
   }
   __device__ static __forceinline__ void post(T (&st)[S], const C&) { st[0] = max_nan(st[0], T(0)); }
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
-    ob[0] = normalize(st[0], c.smin[0], c.smax[0]);
+    ob[0] = normalize_field(c, 0, st[0]);
   }
 };
 
 // ---- PMSM (linear dq-frame model): pmsm_env.py:509-523 ; P = (p,r_s,l_d,l_q,psi_p,u_dc,deadtime)
 //      state = (u_d_buffer,u_q_buffer,epsilon,i_d,i_q,torque,omega_el) ; y = (i_d,i_q,eps)
 template <typename T> struct Pmsm {
-  static constexpr int ID = EXCENV_PMSM, S = 7, A = 2, O = 8, P = 7, NY = 3;
+  static constexpr int ID = EXCENV_PMSM, S = 7, A = 2, O = 8, P = 7, NY = 3, ND = 2;
   static constexpr bool IS_PMSM = true;
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, Pmsm>;
+  __device__ static __forceinline__ void prep(C& c) {
+    c.den[0].init(c.P[2]);  // l_d
+    c.den[1].init(c.P[3]);  // l_q
+  }
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[3]; y[1] = st[4]; y[2] = st[2]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[3] = y[0]; st[4] = y[1]; st[2] = y[2]; }
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&st)[S], T (&dy)[NY]) {
     const T r_s = c.P[1], l_d = c.P[2], l_q = c.P[3], psi_p = c.P[4];
     const T omega_el = st[6];
-    dy[0] = (u[0] + omega_el * l_q * y[1] - r_s * y[0]) / l_d;
-    dy[1] = (u[1] - omega_el * (l_d * y[0] + psi_p) - r_s * y[1]) / l_q;
+    dy[0] = c.den[0].div(u[0] + omega_el * l_q * y[1] - r_s * y[0]);             // / l_d
+    dy[1] = c.den[1].div(u[1] - omega_el * (l_d * y[0] + psi_p) - r_s * y[1]);  // / l_q
     dy[2] = omega_el;
   }
   // pmsm_env.py:365-375
@@ -193,14 +219,14 @@ template <typename T> struct Pmsm {
   template <class CC> __device__ static __forceinline__ void observe(const T (&st)[S], const CC& c, T (&ob)[O]) {
     T sn, cs;
     sincos_t(st[2], sn, cs);
-    ob[0] = normalize(st[3], c.smin[3], c.smax[3]);
-    ob[1] = normalize(st[4], c.smin[4], c.smax[4]);
-    ob[2] = normalize(st[6], c.smin[6], c.smax[6]);
-    ob[3] = normalize(st[5], c.smin[5], c.smax[5]);
+    ob[0] = normalize_field(c, 3, st[3]);
+    ob[1] = normalize_field(c, 4, st[4]);
+    ob[2] = normalize_field(c, 6, st[6]);
+    ob[3] = normalize_field(c, 5, st[5]);
     ob[4] = cs;
     ob[5] = sn;
-    ob[6] = normalize(st[0], c.smin[0], c.smax[0]);
-    ob[7] = normalize(st[1], c.smin[1], c.smax[1]);
+    ob[6] = normalize_field(c, 0, st[0]);
+    ob[7] = normalize_field(c, 1, st[1]);
   }
 
   // pmsm_env.py:92-102 apply_hex_constraint. The sector bits idx_k = [sin(angle(c) - 2*pi*k/3) >= 0] are taken
@@ -259,10 +285,11 @@ template <typename T> struct Pmsm {
 // ---- PMSM saturated model: nonlinear_ode (pmsm_env.py:487-507), currents_to_torque_saturated (:377-381) -----------
 // Everything else (action path, dead time, observation) is the linear model's.
 template <typename T> struct PmsmSat {
-  static constexpr int ID = EXCENV_PMSM, S = 7, A = 2, O = 8, P = 7, NY = 3;
+  static constexpr int ID = EXCENV_PMSM, S = 7, A = 2, O = 8, P = 7, NY = 3, ND = 0;
   static constexpr bool IS_PMSM = true;
   static constexpr bool HAS_LUT = true;
   using C = Ctx<T, PmsmSat>;
+  __device__ static __forceinline__ void prep(C&) {}
   using L = Pmsm<T>;
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[3]; y[1] = st[4]; y[2] = st[2]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[3] = y[0]; st[4] = y[1]; st[2] = y[2]; }

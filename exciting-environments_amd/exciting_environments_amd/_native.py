@@ -89,7 +89,7 @@ def lib():
         l.excenv_sim_ahead_workspace_bytes.restype = ctypes.c_int64
         l.excenv_truncated_width.restype = ctypes.c_int32
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
-                   "excenv_probe_math", "excenv_rew_trunc_term", "excenv_state_from_observation"):
+                   "excenv_probe_math", "excenv_probe_div", "excenv_rew_trunc_term", "excenv_state_from_observation"):
             getattr(l, fn).restype = ctypes.c_int
         vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
         # typed prototypes: plain Python ints / floats / None / byref() pass without per-call ctypes wrapping
@@ -331,3 +331,18 @@ def probe_math(which: int, x: torch.Tensor) -> torch.Tensor:
                                      ctypes.c_void_p(stream))
     _check(rc, "excenv_probe_math")
     return out
+
+
+def probe_div(num: torch.Tensor, den: torch.Tensor):
+    """(InvDiv(den).div(num), num / den) element-wise on the device (tests: equal bits)."""
+    _require_device(num, "probe_div")
+    num, den = num.contiguous(), den.contiguous()
+    assert num.shape == den.shape and num.dtype == den.dtype
+    fast, ref = torch.empty_like(num), torch.empty_like(num)
+    with torch.cuda.device(num.device):
+        stream = torch.cuda.current_stream(num.device).cuda_stream
+        rc = lib().excenv_probe_div(ctypes.c_int(dtype_id(num.dtype)), ctypes.c_int64(num.numel()), ctypes.c_void_p(num.data_ptr()),
+                                    ctypes.c_void_p(den.data_ptr()), ctypes.c_void_p(fast.data_ptr()),
+                                    ctypes.c_void_p(ref.data_ptr()), ctypes.c_void_p(stream))
+    _check(rc, "excenv_probe_div")
+    return fast, ref

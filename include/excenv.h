@@ -239,6 +239,10 @@ int excenv_state_from_observation(int env, int dtype, int64_t B, const excenv_pr
 int excenv_probe_math(int which /*0 sin,1 cos,2 wrap_angle*/, int dtype, int64_t n,
                       const void* in, void* out, void* stream);
 
+/* out_fast[i] = the kernels' division by a loop-invariant denominator (devmath.hpp InvDiv) of num[i] by den[i];
+ * out_ref[i] = num[i] / den[i] as the compiler expands it. Tests assert equal bits. */
+int excenv_probe_div(int dtype, int64_t n, const void* num, const void* den, void* out_fast, void* out_ref, void* stream);
+
 #define EXCENV_OK 0
 #define EXCENV_EINVAL (-1)  /* bad enum / size / combination */
 #define EXCENV_ENULL (-2)   /* required pointer is NULL */

@@ -548,3 +548,49 @@ def test_device_wrap_angle_is_python_modulo_bit_exact():
         assert np.array_equal(got, want), (dt, int((got != want).sum()))
         for bad in (np.nan, np.inf, -np.inf):
             assert np.isnan(_native.probe_math(2, torch.tensor([bad], dtype=dt).cuda()).item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_invariant_division_has_the_bits_of_plain_division(dtype):
+    """devmath.hpp InvDiv (division by a loop-invariant denominator: precomputed refined reciprocal + the compiler's own
+    residual FMAs) against `a / b` as hipcc expands it, bit for bit: random operands over the whole exponent range, operands
+    in the moderate range the fast path serves, exact quotients, and the special values (0, -0, inf, nan, denormals)."""
+    from exciting_environments_amd import _native
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    n = 1 << 22
+    fi = torch.finfo(dtype)
+    it = torch.int32 if dtype == torch.float32 else torch.int64
+
+    def rand_float(lo_exp, hi_exp):
+        m = torch.rand(n, generator=g, dtype=dtype, device="cuda") + 1.0
+        e = torch.randint(lo_exp, hi_exp + 1, (n,), generator=g, device="cuda")
+        s = torch.randint(0, 2, (n,), generator=g, device="cuda").to(dtype) * 2 - 1
+        return torch.ldexp(m * s, e)
+
+    emax = 126 if dtype == torch.float32 else 1021
+    cases = [
+        (rand_float(-20, 20), rand_float(-20, 20)),                      # the regime of the environments
+        (rand_float(-emax, emax), rand_float(-emax, emax)),              # everything, incl. overflow / underflow of the quotient
+        (rand_float(-emax, emax), rand_float(-30, 30)),
+        (rand_float(-30, 30) * 0 + rand_float(0, 0), rand_float(-10, 10)),
+    ]
+    a = rand_float(-8, 8)
+    b = torch.round(rand_float(0, 6))
+    cases.append((a * b, b))                                             # exactly representable quotients
+    special = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), fi.tiny, -fi.tiny, fi.tiny / 8, fi.max, -fi.max,
+                            1.0, -1.0, 3.0, 1e-30 if dtype == torch.float32 else 1e-300, fi.eps], dtype=dtype, device="cuda")
+    sa, sb = torch.meshgrid(special, special, indexing="ij")
+    cases.append((sa.reshape(-1), sb.reshape(-1)))
+    cases.append((rand_float(-20, 20), special[torch.randint(0, special.numel(), (n,), generator=g, device="cuda")]))
+    cases.append((special[torch.randint(0, special.numel(), (n,), generator=g, device="cuda")], rand_float(-20, 20)))
+    for num, den in cases:
+        fast, ref = _native.probe_div(num, den)
+        both_nan = torch.isnan(fast) & torch.isnan(ref)
+        same = (fast.view(it) == ref.view(it)) | both_nan
+        assert bool(same.all()), (num[~same][:4], den[~same][:4], fast[~same][:4], ref[~same][:4])
+    # and the compiler's division is the correctly rounded one (what the CPU oracle computes)
+    num, den = cases[0]
+    fast, _ = _native.probe_div(num, den)
+    assert np.array_equal(fast.cpu().numpy(), num.cpu().numpy() / den.cpu().numpy())
