@@ -61,8 +61,10 @@ template <> struct InvDivLimits<double> {
 
 template <typename T> struct InvDiv {
   T b, y;  // denominator; refined reciprocal (NaN when b is outside the moderate range -> every division takes `a / b`)
-  __device__ __forceinline__ void init(T b_) {
+  __device__ __forceinline__ void init(T b_, bool fast) {
     b = b_;
+    y = T(0);
+    if (!fast) return;
     T r;
     if constexpr (sizeof(T) == 4) {
       const T y0 = __builtin_amdgcn_rcpf(b);
@@ -78,7 +80,10 @@ template <typename T> struct InvDiv {
     const T ab = xabs(b);
     y = (ab >= InvDivLimits<T>::b_lo && ab <= InvDivLimits<T>::b_hi) ? r : __builtin_nan("");
   }
-  __device__ __forceinline__ T div(T a) const {
+  // `fast` is a per-kernel compile-time constant carried in the Ctx (false on the one-step-per-launch path, where the
+  // reciprocal would be set up and used once: plain division is cheaper there)
+  __device__ __forceinline__ T div(T a, bool fast) const {
+    if (!fast) return a / b;
     T q = a * y;
     if constexpr (sizeof(T) == 4) {
       const T r0 = xfma(-b, q, a);

@@ -72,8 +72,9 @@ template <typename T, class M> struct SimArgs {
   int64_t g_sb, g_sk, t_sb, t_sk, t_sc;
 };
 
-template <bool BATCHED, typename T, class M>
+template <bool BATCHED, typename T, class M, bool FASTDIV = true>
 __device__ __forceinline__ void load_ctx(Ctx<T, M>& c, const KProps<T, M>& kp, int64_t i, T dt, T env_tau, T adv_coef) {
+  c.fastdiv = FASTDIV;
   auto get = [&](int j) -> T {
     if constexpr (BATCHED) {
       const T* p = kp.ptr[j];
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
   const unsigned lane_env = threadIdx.x * V;
   const int64_t i = blk0 + lane_env;
   Ctx<T, M> c;
-  load_ctx<GENERAL>(c, ka.kp, (i < ka.B) ? i : 0, ka.dt, ka.env_tau, ka.adv_coef);
+  load_ctx<GENERAL, T, M, false>(c, ka.kp, (i < ka.B) ? i : 0, ka.dt, ka.env_tau, ka.adv_coef);  // one step: plain division
   stage_lut<M, T>(c, ka.kp);
   if (i >= ka.B) return;
   T st[V][S], a[V * A], ob[V * O];
@@ -549,7 +550,7 @@ template <class M, typename T> __global__ void __launch_bounds__(BLOCK) traj_gym
   if (fast >= nfast) return;
   const int64_t b = ka.fast_is_env ? fast : slow, n = ka.fast_is_env ? slow : fast;
   Ctx<T, M> c;
-  load_ctx<true>(c, ka.kp, b, T(0), T(0), T(0));
+  load_ctx<true, T, M, false>(c, ka.kp, b, T(0), T(0), T(0));
   T st[S], ob[O], rref[EXCENV_MAX_CONTROL];
 #pragma unroll
   for (int j = 0; j < S; ++j) st[j] = ka.straj[j][b * ka.s_sb + n * ka.s_sk];
@@ -584,7 +585,7 @@ template <class M, typename T> __global__ void __launch_bounds__(BLOCK) from_obs
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= ka.B) return;
   Ctx<T, M> c;
-  load_ctx<true>(c, ka.kp, i, T(0), T(0), T(0));
+  load_ctx<true, T, M, false>(c, ka.kp, i, T(0), T(0), T(0));
   const T* row = ka.obs + i * (O + ka.n_control);
   T nrm[S];
   if constexpr (M::IS_PMSM) {  // obs = [i_d, i_q, omega_el, torque, cos eps, sin eps, u_d_buffer, u_q_buffer]
@@ -633,8 +634,8 @@ template <typename T> __global__ void probe_div_kernel(int64_t n, const T* num, 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   InvDiv<T> d;
-  d.init(den[i]);
-  out_fast[i] = d.div(num[i]);
+  d.init(den[i], true);
+  out_fast[i] = d.div(num[i], true);
   out_ref[i] = num[i] / den[i];
 }
 

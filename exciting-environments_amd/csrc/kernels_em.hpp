@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
           T* row = wg_obs + off;
           if constexpr (BATCHED) {  // general path: env e's own normalisation bounds / reference columns
             Ctx<T, M> ce;
-            load_ctx<true>(ce, ka.kp, b0 + e, ka.dt, ka.env_tau, ka.adv_coef);
+            load_ctx<true, T, M, false>(ce, ka.kp, b0 + e, ka.dt, ka.env_tau, ka.adv_coef);  // used once: plain division
             M::observe(fs, ce, ob);
 #pragma unroll
             for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {

@@ -23,16 +23,17 @@ template <typename T, class M> struct Ctx {
   // loop-invariant denominators (devmath.hpp InvDiv): (smax - smin) of every state field (normalisation) and the model's own
   InvDiv<T> nrm[M::S];
   InvDiv<T> den[M::ND > 0 ? M::ND : 1];
+  bool fastdiv;  // compile-time constant per kernel (set by load_ctx): trajectory kernels true, step kernel false
 };
 
 // utils.py:13-17 with the state field's precomputed (smax - smin): same operation order, same bits as normalize()
 template <typename T, class M> __device__ __forceinline__ T normalize_field(const Ctx<T, M>& c, int j, T x) {
-  return c.nrm[j].div(T(2) * (x - c.smin[j])) - T(1);
+  return c.nrm[j].div(T(2) * (x - c.smin[j]), c.fastdiv) - T(1);
 }
 
 template <typename T, class M> __device__ __forceinline__ void prep_ctx(Ctx<T, M>& c) {
 #pragma unroll
-  for (int j = 0; j < M::S; ++j) c.nrm[j].init(c.smax[j] - c.smin[j]);
+  for (int j = 0; j < M::S; ++j) c.nrm[j].init(c.smax[j] - c.smin[j], c.fastdiv);
   M::prep(c);
 }
 
@@ -42,12 +43,12 @@ template <typename T> struct Pendulum {
   static constexpr bool IS_PMSM = false;
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, Pendulum>;
-  __device__ static __forceinline__ void prep(C& c) { c.den[0].init(c.P[2] * (c.P[1] * c.P[1])); }  // m * (l * l)
+  __device__ static __forceinline__ void prep(C& c) { c.den[0].init(c.P[2] * (c.P[1] * c.P[1]), c.fastdiv); }  // m * (l * l)
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; y[1] = st[1]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; st[1] = y[1]; }
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
     const T g = c.P[0], l = c.P[1], m = c.P[2];
-    dy[1] = c.den[0].div(u[0] + l * m * g * sin_t(y[0]));  // / (m * (l * l))
+    dy[1] = c.den[0].div(u[0] + l * m * g * sin_t(y[0]), c.fastdiv);  // / (m * (l * l))
     dy[0] = y[1];
   }
   __device__ static __forceinline__ void post(T (&st)[S], const C&) { st[0] = wrap_angle(st[0]); }
@@ -63,12 +64,12 @@ template <typename T> struct MassSpringDamper {
   static constexpr bool IS_PMSM = false;
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, MassSpringDamper>;
-  __device__ static __forceinline__ void prep(C& c) { c.den[0].init(c.P[2]); }  // m
+  __device__ static __forceinline__ void prep(C& c) { c.den[0].init(c.P[2], c.fastdiv); }  // m
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; y[1] = st[1]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; st[1] = y[1]; }
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
     const T d = c.P[0], k = c.P[1];
-    dy[1] = c.den[0].div(u[0] - d * y[1] - k * y[0]);  // / m
+    dy[1] = c.den[0].div(u[0] - d * y[1] - k * y[0], c.fastdiv);  // / m
     dy[0] = y[1];
   }
   __device__ static __forceinline__ void post(T (&)[S], const C&) {}
@@ -85,8 +86,8 @@ template <typename T> struct CartPole {
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, CartPole>;
   __device__ static __forceinline__ void prep(C& c) {
-    c.den[0].init(c.P[4] + c.P[3]);  // m_c + m_p
-    c.den[1].init(c.P[3] * c.P[2]);  // m_p * l
+    c.den[0].init(c.P[4] + c.P[3], c.fastdiv);  // m_c + m_p
+    c.den[1].init(c.P[3] * c.P[2], c.fastdiv);  // m_p * l
   }
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) {
 #pragma unroll
@@ -103,10 +104,10 @@ template <typename T> struct CartPole {
     sincos_t(theta, s, co);
     const auto& by_mass = c.den[0];  // / (m_c + m_p)
     const T d_omega =
-        (g * s + co * by_mass.div(-u[0] - m_p * l * (omega * omega) * s + mu_c * sign_of(velocity)) -
-         c.den[1].div(mu_p * omega)) /
-        (l * (T(4.0 / 3.0) - by_mass.div(m_p * (co * co))));
-    const T d_velocity = by_mass.div(u[0] + m_p * l * ((omega * omega) * s - d_omega * co) - mu_c * sign_of(velocity));
+        (g * s + co * by_mass.div(-u[0] - m_p * l * (omega * omega) * s + mu_c * sign_of(velocity), c.fastdiv) -
+         c.den[1].div(mu_p * omega, c.fastdiv)) /
+        (l * (T(4.0 / 3.0) - by_mass.div(m_p * (co * co), c.fastdiv)));
+    const T d_velocity = by_mass.div(u[0] + m_p * l * ((omega * omega) * s - d_omega * co) - mu_c * sign_of(velocity), c.fastdiv);
     dy[0] = velocity;
     dy[1] = d_velocity;
     dy[2] = omega;
@@ -171,13 +172,13 @@ template <typename T> struct FluidTank {
   static constexpr bool IS_PMSM = false;
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, FluidTank>;
-  __device__ static __forceinline__ void prep(C& c) { c.den[0].init(c.P[0]); }  // base_area
+  __device__ static __forceinline__ void prep(C& c) { c.den[0].init(c.P[0], c.fastdiv); }  // base_area
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[0]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[0] = y[0]; }
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&)[S], T (&dy)[NY]) {
     const T base_area = c.P[0], orifice_area = c.P[1], c_d = c.P[2], g = c.P[3];
     const T h = max_nan(y[0], T(0));
-    dy[0] = c.den[0].div(u[0]) - c_d * orifice_area / base_area * xsqrt(T(2) * g * h);
+    dy[0] = c.den[0].div(u[0], c.fastdiv) - c_d * orifice_area / base_area * xsqrt(T(2) * g * h);
   }
   __device__ static __forceinline__ void post(T (&st)[S], const C&) { st[0] = max_nan(st[0], T(0)); }
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
@@ -193,16 +194,16 @@ template <typename T> struct Pmsm {
   static constexpr bool HAS_LUT = false;
   using C = Ctx<T, Pmsm>;
   __device__ static __forceinline__ void prep(C& c) {
-    c.den[0].init(c.P[2]);  // l_d
-    c.den[1].init(c.P[3]);  // l_q
+    c.den[0].init(c.P[2], c.fastdiv);  // l_d
+    c.den[1].init(c.P[3], c.fastdiv);  // l_q
   }
   __device__ static __forceinline__ void get_y(const T (&st)[S], T (&y)[NY]) { y[0] = st[3]; y[1] = st[4]; y[2] = st[2]; }
   __device__ static __forceinline__ void set_y(T (&st)[S], const T (&y)[NY]) { st[3] = y[0]; st[4] = y[1]; st[2] = y[2]; }
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&st)[S], T (&dy)[NY]) {
     const T r_s = c.P[1], l_d = c.P[2], l_q = c.P[3], psi_p = c.P[4];
     const T omega_el = st[6];
-    dy[0] = c.den[0].div(u[0] + omega_el * l_q * y[1] - r_s * y[0]);             // / l_d
-    dy[1] = c.den[1].div(u[1] - omega_el * (l_d * y[0] + psi_p) - r_s * y[1]);  // / l_q
+    dy[0] = c.den[0].div(u[0] + omega_el * l_q * y[1] - r_s * y[0], c.fastdiv);             // / l_d
+    dy[1] = c.den[1].div(u[1] - omega_el * (l_d * y[0] + psi_p) - r_s * y[1], c.fastdiv);  // / l_q
     dy[2] = omega_el;
   }
   // pmsm_env.py:365-375

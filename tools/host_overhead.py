@@ -19,12 +19,15 @@ for name in ("PENDULUM", "PMSM"):
     for _ in range(50):
         obs, state = env.vmap_step(state, act)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
     n = 3000
-    for _ in range(n):
-        obs, state = env.vmap_step(state, act)
-    torch.cuda.synchronize()
-    print(f"{name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per vmap_step (B=1024, eager)")
+    best = float("inf")
+    for _ in range(3):  # the first timed loop of a process runs ~2x slower (clocks / allocator warm-up): report the best of 3
+        t0 = time.perf_counter()
+        for _ in range(n):
+            obs, state = env.vmap_step(state, act)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n)
+    print(f"{name}: {best * 1e6:.1f} us per vmap_step (B=1024, eager, best of 3 x {n})")
     # HIP graph replay of 16 chained steps
     g = torch.cuda.CUDAGraph()
     s_in = state
