@@ -1,0 +1,13 @@
+set -e
+mkdir -p gpurun_out/r2k
+bash tools/profile_gpu.sh r02_c3_pmsm_euler_f32 > gpurun_out/r2k/prof_c3.log 2>&1
+bash tools/profile_gpu.sh r02_c2_pendulum_euler_f32 --workload pendulum_euler_f32 > gpurun_out/r2k/prof_c2.log 2>&1
+bash tools/profile_gpu.sh r02_c4_msd_tsit5_f64 --workload msd_tsit5_f64 > gpurun_out/r2k/prof_c4.log 2>&1
+bash tools/profile_gpu.sh r02_pmsm_tsit5_f32 --workload pmsm_tsit5_f32 > gpurun_out/r2k/prof_pt.log 2>&1
+bash tools/profile_gpu.sh r02_acrobot_tsit5_f32 --workload acrobot_tsit5_f32 > gpurun_out/r2k/prof_at.log 2>&1
+bash tools/profile_gpu.sh r02_pmsm_step --path step > gpurun_out/r2k/prof_step.log 2>&1
+python bench.py > gpurun_out/r2k/bench_default.json 2> gpurun_out/r2k/bench_default.err
+for w in msd_euler_f32 tank_euler_f32 cartpole_euler_f32 acrobot_euler_f32 pmsm_euler_f64 pmsm_rk4_f32 pmsm_sat_euler_f32 pmsm_sat_tsit5_f32; do
+  python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r2k/$w.json 2>> gpurun_out/r2k/err.txt
+done
+python bench.py --obs-only --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r2k/pmsm_obsonly.json 2>> gpurun_out/r2k/err.txt
