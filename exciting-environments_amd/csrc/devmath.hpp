@@ -80,6 +80,20 @@ template <typename T> struct InvDiv {
     const T ab = xabs(b);
     y = (ab >= InvDivLimits<T>::b_lo && ab <= InvDivLimits<T>::b_hi) ? r : __builtin_nan("");
   }
+  // The fast quotient alone + its "needs the plain division" flag OR-ed into `slow`: lets a caller issue several
+  // independent divisions as straight-line code and test once (div_all below).
+  __device__ __forceinline__ T fastq(T a, bool& slow) const {
+    T q = a * y;
+    if constexpr (sizeof(T) == 4) {
+      const T r0 = xfma(-b, q, a);
+      q = xfma(r0, y, q);
+    }
+    const T r1 = xfma(-b, q, a);
+    q = xfma(r1, y, q);
+    const T aq = xabs(q);
+    slow = slow || !(aq >= InvDivLimits<T>::q_lo && aq <= InvDivLimits<T>::q_hi);
+    return q;
+  }
   // `fast` is a per-kernel compile-time constant carried in the Ctx (false on the one-step-per-launch path, where the
   // reciprocal would be set up and used once: plain division is cheaper there)
   __device__ __forceinline__ T div(T a, bool fast) const {
@@ -100,6 +114,23 @@ template <typename T> struct InvDiv {
     return q;
   }
 };
+
+// N independent divisions num[j] / d[j]->b with ONE wave-uniform test: out[j] has the bits of the plain division.
+template <int N, typename T>
+__device__ __forceinline__ void div_all(const InvDiv<T>* const (&d)[N], const T (&num)[N], T (&out)[N], bool fast) {
+  if (!fast) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) out[j] = num[j] / d[j]->b;
+    return;
+  }
+  bool slow = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) out[j] = d[j]->fastq(num[j], slow);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) out[j] = num[j] / d[j]->b;  // every lane: same bits as the fast path where that was valid
+  }
+}
 
 // Exact C fmod(|x|, Y) for the compile-time divisor Y = 2*pi, without the library's bit-serial loop:
 // the truncated quotient is estimated with a reciprocal multiply (off by at most one for |q| < 2^22),

@@ -31,6 +31,21 @@ template <typename T, class M> __device__ __forceinline__ T normalize_field(cons
   return c.nrm[j].div(T(2) * (x - c.smin[j]), c.fastdiv) - T(1);
 }
 
+// N state fields normalised at once (one validity test for all their divisions): out[j] = normalize(x[j]; field F[j])
+template <int N, typename T, class M>
+__device__ __forceinline__ void normalize_fields(const Ctx<T, M>& c, const int (&F)[N], const T (&x)[N], T (&out)[N]) {
+  const InvDiv<T>* d[N];
+  T num[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    d[j] = &c.nrm[F[j]];
+    num[j] = T(2) * (x[j] - c.smin[F[j]]);
+  }
+  div_all<N, T>(d, num, out, c.fastdiv);
+#pragma unroll
+  for (int j = 0; j < N; ++j) out[j] = out[j] - T(1);
+}
+
 template <typename T, class M> __device__ __forceinline__ void prep_ctx(Ctx<T, M>& c) {
 #pragma unroll
   for (int j = 0; j < M::S; ++j) c.nrm[j].init(c.smax[j] - c.smin[j], c.fastdiv);
@@ -53,8 +68,8 @@ template <typename T> struct Pendulum {
   }
   __device__ static __forceinline__ void post(T (&st)[S], const C&) { st[0] = wrap_angle(st[0]); }
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
-    ob[0] = normalize_field(c, 0, st[0]);
-    ob[1] = normalize_field(c, 1, st[1]);
+    const int F[2] = {0, 1};
+    normalize_fields<2>(c, F, st, ob);
   }
 };
 
@@ -74,8 +89,8 @@ template <typename T> struct MassSpringDamper {
   }
   __device__ static __forceinline__ void post(T (&)[S], const C&) {}
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
-    ob[0] = normalize_field(c, 0, st[0]);
-    ob[1] = normalize_field(c, 1, st[1]);
+    const int F[2] = {0, 1};
+    normalize_fields<2>(c, F, st, ob);
   }
 };
 
@@ -115,8 +130,8 @@ template <typename T> struct CartPole {
   }
   __device__ static __forceinline__ void post(T (&st)[S], const C&) { st[2] = wrap_angle(st[2]); }
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ob[j] = normalize_field(c, j, st[j]);
+    const int F[4] = {0, 1, 2, 3};
+    normalize_fields<4>(c, F, st, ob);
   }
 };
 
@@ -161,8 +176,8 @@ template <typename T> struct Acrobot {
     st[1] = wrap_angle(st[1]);
   }
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ob[j] = normalize_field(c, j, st[j]);
+    const int F[4] = {0, 1, 2, 3};
+    normalize_fields<4>(c, F, st, ob);
   }
 };
 
@@ -202,8 +217,12 @@ template <typename T> struct Pmsm {
   __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&st)[S], T (&dy)[NY]) {
     const T r_s = c.P[1], l_d = c.P[2], l_q = c.P[3], psi_p = c.P[4];
     const T omega_el = st[6];
-    dy[0] = c.den[0].div(u[0] + omega_el * l_q * y[1] - r_s * y[0], c.fastdiv);             // / l_d
-    dy[1] = c.den[1].div(u[1] - omega_el * (l_d * y[0] + psi_p) - r_s * y[1], c.fastdiv);  // / l_q
+    const InvDiv<T>* d[2] = {&c.den[0], &c.den[1]};  // / l_d, / l_q
+    const T num[2] = {u[0] + omega_el * l_q * y[1] - r_s * y[0], u[1] - omega_el * (l_d * y[0] + psi_p) - r_s * y[1]};
+    T q[2];
+    div_all<2, T>(d, num, q, c.fastdiv);
+    dy[0] = q[0];
+    dy[1] = q[1];
     dy[2] = omega_el;
   }
   // pmsm_env.py:365-375
@@ -220,14 +239,18 @@ template <typename T> struct Pmsm {
   template <class CC> __device__ static __forceinline__ void observe(const T (&st)[S], const CC& c, T (&ob)[O]) {
     T sn, cs;
     sincos_t(st[2], sn, cs);
-    ob[0] = normalize_field(c, 3, st[3]);
-    ob[1] = normalize_field(c, 4, st[4]);
-    ob[2] = normalize_field(c, 6, st[6]);
-    ob[3] = normalize_field(c, 5, st[5]);
+    const int F[6] = {3, 4, 6, 5, 0, 1};
+    const T x[6] = {st[3], st[4], st[6], st[5], st[0], st[1]};
+    T n[6];
+    normalize_fields<6>(c, F, x, n);
+    ob[0] = n[0];
+    ob[1] = n[1];
+    ob[2] = n[2];
+    ob[3] = n[3];
     ob[4] = cs;
     ob[5] = sn;
-    ob[6] = normalize_field(c, 0, st[0]);
-    ob[7] = normalize_field(c, 1, st[1]);
+    ob[6] = n[4];
+    ob[7] = n[5];
   }
 
   // pmsm_env.py:92-102 apply_hex_constraint. The sector bits idx_k = [sin(angle(c) - 2*pi*k/3) >= 0] are taken
