@@ -19,12 +19,9 @@ namespace excenv {
 #ifndef EXCENV_EM_TK
 #define EXCENV_EM_TK 16  // solver steps staged per tile for 4-byte elements (8-byte elements: half, same LDS bytes)
 #endif
-// Observation rows are written as non-temporal stores (+6-10 %): complete 128-byte lines that nothing reads back. The state
-// leaves and the action loads stay cacheable — non-temporal state stores measured -40 %, non-temporal action loads -30 %: the
-// L2 merges part of the state leaves' partial bursts and re-serves the action lines shared by consecutive tiles.
-#ifndef EXCENV_EM_NT_OBS
-#define EXCENV_EM_NT_OBS 1
-#endif
+// Observation rows are written as non-temporal stores: complete lines that nothing reads back. The state leaves and the
+// action loads stay cacheable — non-temporal state stores measured -40 %, non-temporal action loads -30 %: the L2 merges
+// part of the state leaves' partial bursts and re-serves the action lines shared by consecutive tiles.
 constexpr int EM_LANES = 64;  // one wave per workgroup
 static_assert((EXCENV_EM_TK & (EXCENV_EM_TK - 1)) == 0 && EXCENV_EM_TK >= 2 && EXCENV_EM_TK <= EM_LANES,
               "EXCENV_EM_TK must be a power of two in [2, 64]");
@@ -136,14 +133,49 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
       }
     }
     __syncthreads();
-    // The next action tile is parked BEFORE the flush: its loads were issued a whole tile ago, so the s_waitcnt in front of
-    // these LDS writes is already satisfied — after the flush the in-order vmcnt would make it wait for every trajectory
-    // store of this tile (a full memory drain per tile). Every lane parks and later reads only its own column of tact.
-    park_actions();
+    // The prefetched action rows must have LANDED before the flush issues its stores: their loads were requested a whole
+    // tile ago, so waiting here costs nothing, whereas a wait after the flush would — vmcnt counts in order — drain every
+    // trajectory store of this tile. The empty asm makes each register a use at this point (the compiler puts its
+    // s_waitcnt here); the rows are parked in LDS after the flush, which borrows the action tile as staging space.
+#pragma unroll
+    for (int t = 0; t < NA; ++t)
+#pragma unroll
+      for (int q = 0; q < A; ++q) asm volatile("" : "+v"(areg[t][q]));
     // ---- flush ----
     // observations: EPR environments per round, lane (fel, ft) re-creates the row of env (r * EPR + fel) at step ft
-#ifndef EXCENV_EM_DEBUG_SKIP_OBS
-    {
+    if constexpr (!BATCHED && (O % VW) == 0) {
+      // Dense form (no control columns, rows made of whole 16-byte pieces): the 64 rows of a round go through a staging
+      // buffer in the (idle) action tile so that every store instruction of the wave writes 64 consecutive pieces = whole
+      // rows of EPR / PR... environments back to back (1 KiB per instruction), non-temporal.
+      constexpr int PR = O / VW;  // 16-byte pieces per row
+      static_assert((TK + 1) * A >= O, "the action tile must be able to stage one round of observation rows");
+      T* const stage = tact;
+      for (int r = 0; r < TK; ++r) {
+        T fs[S], ob[O];
+#pragma unroll
+        for (int j = 0; j < S; ++j) fs[j] = tst[(j * EM_LANES + r * EPR + fel) * LDS_ + ft];
+        M::observe(fs, c, ob);
+#pragma unroll
+        for (int q = 0; q < O; q += VW) {
+          T v[VW];
+#pragma unroll
+          for (int h = 0; h < VW; ++h) v[h] = ob[q + h];
+          store_v<T, VW>(stage + lane * O + q, v);  // row index within the round == lane (fel * TK + ft)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PR; ++i) {
+          const int p = lane + EM_LANES * i;  // piece index in round order == memory order within each environment
+          const int row = p / PR, piece = p % PR;
+          const int el = row / TK, step = row % TK, e = r * EPR + el;
+          T v[VW];
+          load_v<T, VW>(stage + p * VW, v);
+          if (step < cnt && e < nenv)
+            store_stream<T, VW>(wg_obs + (unsigned)((e * (N + 1) + n0 + step) * O + piece * VW), v);
+        }
+        __syncthreads();
+      }
+    } else {
       unsigned off = (unsigned)((fel * (N + 1) + n0 + ft) * OW);
       for (int r = 0; r < TK; ++r, off += obs_round) {
         const int e = r * EPR + fel;
@@ -174,11 +206,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
               T v[VW];
 #pragma unroll
               for (int h = 0; h < VW; ++h) v[h] = ob[q + h];
-#if EXCENV_EM_NT_OBS
-              store_stream<T, VW>(row + q, v);  // full 128-byte lines once the round is complete: no reason to keep them in L2
-#else
               store_v<T, VW>(row + q, v);
-#endif
             }
           } else {
 #pragma unroll
@@ -187,9 +215,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
         }
       }
     }
-#endif
     // state leaves: TK rounds per leaf, all LDS reads of a leaf in flight before its stores
-#ifndef EXCENV_EM_DEBUG_SKIP_STATES
     if (with_states) {
       const unsigned off0 = (unsigned)(fel * (N + 1) + n0 + ft);
 #pragma unroll
@@ -206,7 +232,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
         }
       }
     }
-#endif
+    park_actions();  // every lane parks and later reads only its own column of tact; the loop-top barrier publishes it
   }
 }
 
