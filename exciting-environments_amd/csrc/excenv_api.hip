@@ -294,6 +294,21 @@ int excenv_state_from_observation(int env, int dtype, int64_t B, const excenv_pr
   return t->from_obs(fc);
 }
 
+int excenv_update_ref(int env, int dtype, int64_t B, const excenv_props_t* props, int32_t n_control,
+                      const int32_t* control_idx, void* const* reference, int64_t* keys, int64_t* hold,
+                      int32_t hold_steps_min, int32_t hold_steps_max, void* stream) {
+  if (int rc = check_common("excenv_update_ref", env, 0, dtype, B)) return rc;
+  if (n_control < 0 || n_control > EXCENV_MAX_CONTROL) { set_error("excenv_update_ref: bad n_control %d", n_control); return EXCENV_EINVAL; }
+  if (!props || !keys || !hold || (n_control > 0 && (!control_idx || !reference))) { set_error("excenv_update_ref: NULL argument"); return EXCENV_ENULL; }
+  for (int j = 0; j < n_control; ++j)
+    if (control_idx[j] < 0 || control_idx[j] >= table_public(env)->S) { set_error("excenv_update_ref: control_idx[%d] out of range", j); return EXCENV_EINVAL; }
+  int trc;
+  const EnvVTable* t = table_for(env, props, &trc);
+  if (!t) return trc;
+  RefGenCall rc{dtype, B, props, n_control, control_idx, reference, keys, hold, hold_steps_min, hold_steps_max, (hipStream_t)stream};
+  return t->update_ref(rc);
+}
+
 int excenv_probe_math(int which, int dtype, int64_t n, const void* in, void* out, void* stream) {
   if (which < 0 || which > 2 || n < 0 || (dtype != EXCENV_F32 && dtype != EXCENV_F64)) { set_error("excenv_probe_math: bad argument"); return EXCENV_EINVAL; }
   if (!in || !out) { set_error("excenv_probe_math: NULL argument"); return EXCENV_ENULL; }

@@ -40,6 +40,7 @@ template <typename T, class M> struct StepArgs {
   int32_t n_control;
   int32_t control_idx[EXCENV_MAX_CONTROL];
   const T* reference[EXCENV_MAX_CONTROL];
+  const T* obs_reference[EXCENV_MAX_CONTROL];  // what the observation columns show (== reference unless the caller says otherwise)
   T dt, env_tau, adv_coef;
   // optional gym outputs (all three or none): reward [B], terminated [B] (0/1 bytes), truncated [B][TW] (0/1 bytes)
   T* reward;
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
         if (j < ka.n_control) {
           T x, lo, hi;
           pick_field<M, T>(st[0], c, ka.control_idx[j], x, lo, hi);
-          row[O + j] = normalize(rref[j], lo, hi);
+          row[O + j] = normalize(ka.obs_reference[j][i], lo, hi);
         }
       }
     }

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include "kernels_em.hpp"
+#include "refgen.hpp"
 
 namespace excenv {
 
@@ -87,12 +88,26 @@ struct FromObsCall {
   hipStream_t stream;
 };
 
+struct RefGenCall {
+  int dtype;
+  int64_t B;
+  const excenv_props_t* props;
+  int32_t n_control;
+  const int32_t* control_idx;
+  void* const* reference;
+  int64_t* keys;
+  int64_t* hold;
+  int32_t hold_min, hold_max;
+  hipStream_t stream;
+};
+
 struct EnvVTable {
   int S, A, O, P;
   int (*step)(const StepCall&);
   int (*sim)(const SimCall&);
   int (*traj_gym)(const TrajGymCall&);
   int (*from_obs)(const FromObsCall&);
+  int (*update_ref)(const RefGenCall&);
 };
 
 template <typename T, class M>
@@ -214,6 +229,7 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
   for (int j = 0; j < ka.n_control; ++j) {
     ka.control_idx[j] = sc.control->control_idx[j];
     ka.reference[j] = (const T*)sc.control->reference[j];
+    ka.obs_reference[j] = sc.control->obs_reference[j] ? (const T*)sc.control->obs_reference[j] : ka.reference[j];
   }
   ka.dt = (T)sc.tau;
   ka.env_tau = (T)sc.tau;
@@ -495,6 +511,26 @@ template <class M, typename T> static int launch_from_obs(const FromObsCall& fc)
   return check_launch("excenv_state_from_observation");
 }
 
+template <class M, typename T> static int launch_update_ref(const RefGenCall& rc) {
+  RefGenArgs<T, M> ka;
+  std::memset(&ka, 0, sizeof(ka));
+  fill_props<T, M>(ka.kp, rc.props);
+  ka.B = rc.B;
+  ka.n_control = rc.n_control;
+  for (int j = 0; j < rc.n_control; ++j) {
+    if (!rc.reference[j]) { set_error("excenv_update_ref: reference pointer %d is NULL", j); return EXCENV_ENULL; }
+    ka.control_idx[j] = rc.control_idx[j];
+    ka.reference[j] = (T*)rc.reference[j];
+  }
+  ka.keys = rc.keys;
+  ka.hold = rc.hold;
+  ka.hold_min = rc.hold_min;
+  ka.hold_max = rc.hold_max;
+  if (rc.B == 0) return EXCENV_OK;
+  hipLaunchKernelGGL((update_ref_kernel<M, T>), dim3((unsigned)((rc.B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, rc.stream, ka);
+  return check_launch("excenv_update_ref");
+}
+
 template <template <typename> class MT> struct EnvEntry {
   static int step(const StepCall& sc) {
     return sc.dtype == EXCENV_F32 ? launch_step<MT<float>, float>(sc) : launch_step<MT<double>, double>(sc);
@@ -508,8 +544,11 @@ template <template <typename> class MT> struct EnvEntry {
   static int from_obs(const FromObsCall& fc) {
     return fc.dtype == EXCENV_F32 ? launch_from_obs<MT<float>, float>(fc) : launch_from_obs<MT<double>, double>(fc);
   }
+  static int update_ref(const RefGenCall& rc) {
+    return rc.dtype == EXCENV_F32 ? launch_update_ref<MT<float>, float>(rc) : launch_update_ref<MT<double>, double>(rc);
+  }
   static EnvVTable vtable() {
-    return EnvVTable{MT<float>::S, MT<float>::A, MT<float>::O, MT<float>::P, &step, &sim, &traj_gym, &from_obs};
+    return EnvVTable{MT<float>::S, MT<float>::A, MT<float>::O, MT<float>::P, &step, &sim, &traj_gym, &from_obs, &update_ref};
   }
 };
 

@@ -61,6 +61,7 @@ class Control(ctypes.Structure):
         ("n_control", ctypes.c_int32),
         ("control_idx", ctypes.c_int32 * MAX_CONTROL),
         ("reference", ctypes.c_void_p * MAX_CONTROL),
+        ("obs_reference", ctypes.c_void_p * MAX_CONTROL),  # gym_step only: NULL = the observation shows `reference`
     ]
 
 
@@ -89,7 +90,8 @@ def lib():
         l.excenv_sim_ahead_workspace_bytes.restype = ctypes.c_int64
         l.excenv_truncated_width.restype = ctypes.c_int32
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
-                   "excenv_probe_math", "excenv_probe_div", "excenv_rew_trunc_term", "excenv_state_from_observation"):
+                   "excenv_probe_math", "excenv_probe_div", "excenv_rew_trunc_term", "excenv_state_from_observation",
+                   "excenv_update_ref"):
             getattr(l, fn).restype = ctypes.c_int
         vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
         # typed prototypes: plain Python ints / floats / None / byref() pass without per-call ctypes wrapping
@@ -196,7 +198,8 @@ def _opts_ref(opts: Optional[LaunchOpts]):
     return ctypes.byref(opts) if opts is not None else None
 
 
-def make_control(control_idx: Sequence[int], refs: Sequence[torch.Tensor]) -> Optional[Control]:
+def make_control(control_idx: Sequence[int], refs: Sequence[torch.Tensor],
+                 obs_refs: Optional[Sequence[torch.Tensor]] = None) -> Optional[Control]:
     if not control_idx:
         return None
     c = Control()
@@ -204,6 +207,8 @@ def make_control(control_idx: Sequence[int], refs: Sequence[torch.Tensor]) -> Op
     for j, (f, r) in enumerate(zip(control_idx, refs)):
         c.control_idx[j] = f
         c.reference[j] = r.data_ptr()
+        if obs_refs is not None:
+            c.obs_reference[j] = obs_refs[j].data_ptr()
     return c
 
 
@@ -297,6 +302,21 @@ def state_from_observation(env_id, dtype, B, props: Props, control_idx: Sequence
             (ctypes.c_int32 * nc)(*control_idx) if nc else None, ctypes.c_void_p(obs.data_ptr()), _ptrs(state_out),
             _ptrs(reference_out) if nc else None, ctypes.c_void_p(_raw_stream(obs.device)))
     _check(rc, "excenv_state_from_observation")
+
+
+def update_ref(env_id, dtype, B, props: Props, control_idx: Sequence[int], reference: Sequence[torch.Tensor],
+               keys: torch.Tensor, hold: torch.Tensor, hold_min: int, hold_max: int):
+    """excenv_update_ref: in-place reference redraw + hold countdown (GymWrapper.update_ref). keys: int64 [B, 2], hold: int64 [B]."""
+    _require_device(keys, "GymWrapper.update_ref")
+    assert keys.dtype == torch.int64 and keys.is_contiguous() and hold.dtype == torch.int64 and hold.is_contiguous()
+    nc = len(control_idx)
+    with _on_device(keys.device):
+        rc = lib().excenv_update_ref(
+            ctypes.c_int(env_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B), ctypes.byref(props), ctypes.c_int32(nc),
+            (ctypes.c_int32 * nc)(*control_idx) if nc else None, _ptrs(reference) if nc else None,
+            ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(hold.data_ptr()), ctypes.c_int32(hold_min), ctypes.c_int32(hold_max),
+            ctypes.c_void_p(_raw_stream(keys.device)))
+    _check(rc, "excenv_update_ref")
 
 
 def sim_ahead_workspace_bytes(env_id, dtype, B, K, substeps, n_control, action_layout, traj_layout,

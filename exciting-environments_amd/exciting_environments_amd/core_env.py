@@ -461,7 +461,7 @@ class CoreEnvironment(ABC):
         per = self.batch_size * (self.physical_state_dim + self._obs_dim() + (1 if gym else 0)) * isz
         return max(1, min(32, (4 << 20) // max(per, 1)))
 
-    def _vmap_step_launch(self, state, action, gym: bool):
+    def _vmap_step_launch(self, state, action, gym: bool, obs_refs=None):
         B = self.batch_size
         dev = self.device
         getter = self._leaf_getter
@@ -488,11 +488,12 @@ class CoreEnvironment(ABC):
         if self.control_state:
             refs = tuple(getattr(state.reference, n) for n in self.control_state)
             cc = self._ctl_cache
-            key = (tuple(self.control_state), tuple(map(id, refs)))
+            key = (tuple(self.control_state), tuple(map(id, refs)), None if obs_refs is None else tuple(map(id, obs_refs)))
             if cc is None or cc[0] != key:
                 tens = [self._t(r, (B,)) for r in refs]
-                ctl = _native.make_control([self.STATE_FIELDS.index(n) for n in self.control_state], tens)
-                cc = self._ctl_cache = (key, refs, tens, ctl, ctypes.byref(ctl))
+                otens = None if obs_refs is None else [self._t(r, (B,)) for r in obs_refs]  # gym_step: obs shows these
+                ctl = _native.make_control([self.STATE_FIELDS.index(n) for n in self.control_state], tens, otens)
+                cc = self._ctl_cache = (key, (refs, obs_refs), (tens, otens), ctl, ctypes.byref(ctl))
             control_ref = cc[4]
         props, _keep = self._props_for(self.env_properties, B)
         capturing = torch._C._cuda_isCurrentStreamCapturing()

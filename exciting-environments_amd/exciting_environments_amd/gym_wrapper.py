@@ -38,6 +38,9 @@ class GymWrapper:
         self.generate_truncated = generate_truncated
         self.generate_terminated = generate_terminated
         self._ref_rng = None
+        self.host_hold_mirror = True  # see gym_step
+        self.device_update_ref = True  # key-stream reference generator as one HIP launch (False: literal torch path)
+        self._hold_min = None
 
     @classmethod
     def from_env(cls, env_type: EnvironmentRegistry, **env_kwargs):
@@ -53,13 +56,32 @@ class GymWrapper:
         return obs, reward, terminated, truncated
 
     def gym_step(self, action, state, reference_hold_steps):
-        """gym_wrapper.py:88-130."""
+        """gym_wrapper.py:88-130: vmap_step, then (reference generator armed) update_ref, then reward / terminated /
+        truncated of the new state.
+
+        With the generator armed a new reference is due only every hold_steps_min..max steps per environment, and drawing
+        one costs a random initial state for the whole batch. The wrapper therefore mirrors the smallest hold counter on
+        the host (one device read whenever references were redrawn): while it is positive no environment can be due, the
+        step is the single fused launch (`excenv_gym_step`) and the counters are decremented; when it reaches zero the step
+        takes the literal path. Same results either way (`test_gym_wrapper_ref_generation_fast_path_equals_literal_path`).
+        The mirror is used only for the wrapper's own counter tensor (`step()`); foreign counters take the literal path."""
         env = self.env
         custom = self.generate_reward or self.generate_terminated or self.generate_truncated
         regen = len(self.control_state) and self.ref_gen
         if not custom and not regen:
             obs, reward, terminated, truncated, state = env.vmap_gym_step(state, action)
             return obs, reward, terminated, truncated, state, reference_hold_steps
+        if (regen and not custom and self._ref_rng is None and _random.is_key(state.PRNGKey) and state.PRNGKey.is_cuda
+                and self.device_update_ref):
+            return self._gym_step_device_refgen(action, state, reference_hold_steps)
+        if regen and not custom and self.host_hold_mirror and reference_hold_steps is self.reference_hold_steps:
+            if self._hold_min is None:
+                self._hold_min = int(reference_hold_steps.min())
+            if self._hold_min > 0:  # nobody is due: update_ref would only count down
+                obs, reward, terminated, truncated, state = env.vmap_gym_step(state, action)
+                self._hold_min -= 1
+                return obs, reward, terminated, truncated, state, reference_hold_steps - 1
+            self._hold_min = None  # somebody is due: literal path below, mirror re-read on the next call
         obs, state = env.vmap_step(state, action)
         if regen:
             state, reference_hold_steps = self.update_ref(state, reference_hold_steps)
@@ -68,6 +90,36 @@ class GymWrapper:
         terminated = (self.generate_terminated or env.generate_terminated)(state, reward, ep)
         truncated = (self.generate_truncated or env.generate_truncated)(state, ep)
         return obs, reward, terminated, truncated, state, reference_hold_steps
+
+    def _gym_step_device_refgen(self, action, state, reference_hold_steps):
+        """Key-stream reference generator on the device: `excenv_update_ref` redraws the due references, new keys and hold
+        counters in one launch (on copies: the inputs stay untouched), then the fused gym launch computes reward / flags
+        against the NEW references while the observation columns show the OLD ones — the reference takes the observation
+        before update_ref and the reward after it (gym_wrapper.py:109-126). Two launches per step instead of the literal
+        path's few hundred elementwise kernels."""
+        from . import _native
+
+        env = self.env
+        B = env.batch_size
+        idx = [env.STATE_FIELDS.index(n) for n in self.control_state]
+        old_refs = [env._t(getattr(state.reference, n), (B,)) for n in self.control_state]
+        new_refs = [r.clone() for r in old_refs]
+        keys = state.PRNGKey.to(device=env.device, dtype=torch.int64).clone().contiguous()
+        hold = reference_hold_steps.to(device=env.device, dtype=torch.int64).reshape(B).clone()
+        props, _keep = env._props_for(env.env_properties, B)
+        _native.update_ref(env.ENV_ID, env.dtype, B, props, idx, new_refs, keys, hold, self.ref_params["hold_steps_min"],
+                           self.ref_params["hold_steps_max"])
+        ref = {n: getattr(state.reference, n) for n in env.STATE_FIELDS}
+        ref.update(dict(zip(self.control_state, new_refs)))
+        state = replace(state, reference=env.PhysicalState(**ref), PRNGKey=keys)
+        if type(action) is not torch.Tensor:
+            action = torch.as_tensor(action)
+        assert action.shape == (B, env.action_dim), (
+            "The action needs to be of shape (batch_size, action_dim) which is "
+            + f"{(B, env.action_dim)}, but {tuple(action.shape)} is given"
+        )
+        obs, reward, terminated, truncated, state = env._vmap_step_launch(state, action, True, obs_refs=old_refs)
+        return obs, reward, terminated, truncated, state, hold.reshape(reference_hold_steps.shape)
 
     def reset(self, rng_env=None, rng_ref=None, initial_state=None):
         """Resets the environment to a default / random / passed initial state and (re)arms the reference generator
@@ -100,11 +152,17 @@ class GymWrapper:
             self.ref_gen = False
             print("Since no PRNGKey for reference was provided, reference generation is deactivated.")
         self.state = state
+        self._hold_min = None
         return env.generate_observation(state, env.env_properties), {}
 
     def update_ref(self, state, hold_steps):
-        """gym_wrapper.py:170-175: draw a new reference where the hold counter reached zero, then count down."""
-        state, hold_steps = self.generate_new_ref(state, hold_steps == 0, hold_steps)
+        """gym_wrapper.py:170-175: draw a new reference where the hold counter reached zero, then count down. Key mode is a
+        pure function of each environment's key. Generator mode shares ONE torch stream across the batch, so it draws only
+        at steps where some environment is due (that keeps the stream independent of how the step was executed)."""
+        due = hold_steps == 0
+        if self._ref_rng is not None and not bool(due.any()):
+            return state, hold_steps - 1
+        state, hold_steps = self.generate_new_ref(state, due, hold_steps)
         return state, hold_steps - 1
 
     def generate_new_ref(self, state, mask, hold_steps):

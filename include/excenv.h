@@ -113,6 +113,10 @@ typedef struct {
   int32_t n_control;
   int32_t control_idx[EXCENV_MAX_CONTROL];
   const void* reference[EXCENV_MAX_CONTROL];
+  /* excenv_gym_step only: NULL, or the [B] reference values the OBSERVATION columns show when they differ from the ones the
+   * reward is computed against — GymWrapper.gym_step takes the observation before update_ref and the reward after it
+   * (gym_wrapper.py:109-126), so in a step that redraws a reference the two differ. */
+  const void* obs_reference[EXCENV_MAX_CONTROL];
 } excenv_control_t;
 
 /* Per-call launch options (no reference counterpart; NULL = all defaults). Everything that shapes a launch travels
@@ -234,6 +238,17 @@ int excenv_rew_trunc_term(int env, int dtype, int64_t B, int64_t rows, const exc
 int excenv_state_from_observation(int env, int dtype, int64_t B, const excenv_props_t* props, int32_t n_control,
                                   const int32_t* control_idx, const void* obs, void* const* state_out,
                                   void* const* reference_out, void* stream);
+
+/* ---- replaces GymWrapper.update_ref / generate_new_ref (gym_wrapper.py:170-192), one thread per environment: where
+ * hold[i] == 0 draw a random initial state from the environment's key (init_state(rng), e.g. pendulum_env.py:270-276, PMSM
+ * pmsm_env.py:402-456 incl. jax.random.ball), copy its controlled fields into reference[j][i], split the key for the new hold
+ * time (jax.random.randint(sub, (1,), hold_steps_min, hold_steps_max), int32 form) and keep the other half as the new key;
+ * then hold[i] -= 1. All arrays are updated in place. keys: [B][2] uint32 key words stored in int64 (jax.random key data);
+ * the samplers restate JAX's published algorithms (threefry2x32 split / bits / uniform / randint / normal / gamma / ball) —
+ * parity with JAX itself is unpinned. */
+int excenv_update_ref(int env, int dtype, int64_t B, const excenv_props_t* props, int32_t n_control,
+                      const int32_t* control_idx, void* const* reference, int64_t* keys, int64_t* hold,
+                      int32_t hold_steps_min, int32_t hold_steps_max, void* stream);
 
 /* ---- device-math probes (tests only): out[i] = f(in[i]) for the in-kernel fp32 routines -- */
 int excenv_probe_math(int which /*0 sin,1 cos,2 wrap_angle*/, int dtype, int64_t n,

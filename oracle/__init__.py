@@ -84,6 +84,7 @@ class Control(ctypes.Structure):
         ("n_control", ctypes.c_int32),
         ("control_idx", ctypes.c_int32 * MAX_CONTROL),
         ("reference", ctypes.c_void_p * MAX_CONTROL),
+        ("obs_reference", ctypes.c_void_p * MAX_CONTROL),  # unused by the oracle (excenv_control_t layout)
     ]
 
 

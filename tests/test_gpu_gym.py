@@ -216,3 +216,89 @@ def test_state_from_observation_kernel_round_trip_and_oracle(env_name, dtype):
     one = env.generate_state_from_observation(obs[5], env.env_properties)
     for n in env.STATE_FIELDS:
         assert torch.allclose(getattr(one.physical_state, n), getattr(back.physical_state, n)[5], rtol=0, atol=tol * 1e3)
+
+
+@pytest.mark.parametrize("key_mode", [True, False])
+@pytest.mark.parametrize("env_name", ["pendulum", "pmsm", "cartpole"])
+def test_gym_wrapper_ref_generation_fast_path_equals_literal_path(env_name, key_mode):
+    """With the reference generator armed the wrapper has three executions of a step: (key mode, device) excenv_update_ref +
+    the fused gym launch; the fused launch alone while the host mirror of the smallest hold counter says nobody is due; the
+    literal vmap_step -> update_ref -> reward path. Same outputs, states, references, keys and counters over several redraws
+    (hold steps 2..4, so a redraw is due every few steps). Rewards (fused kernel vs torch mirror) and, for PMSM, everything
+    downstream of jax.random.ball (device libm vs torch erfinv / log) are compared with a tolerance."""
+    from exciting_environments_amd import GymWrapper
+    from exciting_environments_amd import random as jr
+
+    B, steps = 64, 40
+    variants = [(True, True), (False, True), (False, False)] if key_mode else [(False, True), (False, False)]
+    runs = []
+    for device_refgen, mirror in variants:
+        env, props, keep, spec = make_env(env_name, B, torch.float32)
+        gw = GymWrapper(env=env, control_state=CONTROL[env_name], ref_params={"hold_steps_min": 2, "hold_steps_max": 5})
+        gw.host_hold_mirror, gw.device_update_ref = mirror, device_refgen
+        rng_ref = jr.PRNGKey(3, device=env.device) if key_mode else 3
+        rng_env = jr.split(jr.PRNGKey(4, device=env.device), B) if key_mode else 4
+        obs, _ = gw.reset(rng_env=rng_env, rng_ref=rng_ref)
+        acts = torch.as_tensor(np.random.default_rng(5).uniform(-1, 1, (steps, B, env.action_dim)).astype(np.float32), device=env.device)
+        out = [("obs", obs)]
+        for k in range(steps):
+            o, r, te, tr = gw.step(acts[k])
+            out += [("obs", o), ("reward", r), ("flag", te.to(torch.float32)), ("flag", tr.to(torch.float32)),
+                    ("hold", gw.reference_hold_steps.to(torch.float32).clone())]
+        out += [("ref", getattr(gw.state.reference, n).clone()) for n in CONTROL[env_name]]
+        out += [("state", getattr(gw.state.physical_state, n).clone()) for n in env.STATE_FIELDS]
+        if key_mode:
+            out.append(("key", gw.state.PRNGKey.to(torch.float64)))
+        runs.append(out)
+    ball = env_name == "pmsm" and key_mode  # references drawn through the gamma-rejection ball: libm-level differences
+    for run in runs[:-1]:
+        assert len(run) == len(runs[-1])
+        for i, ((kind, a), (_, b)) in enumerate(zip(run, runs[-1])):
+            if kind in ("hold", "key", "state") or (kind in ("obs", "ref") and not ball):
+                assert torch.equal(a, b), (i, kind)
+            elif kind == "flag":
+                assert float((a != b).float().mean()) <= (0.02 if ball else 0.0), (i, kind)
+            else:
+                assert torch.allclose(a, b, rtol=2e-5, atol=2e-5), (i, kind, float((a - b).abs().max()))
+    holds = torch.stack([t for kind, t in runs[0] if kind == "hold"])  # the counters really ran down and were redrawn
+    assert int(holds.min()) >= 0 and float(holds.max()) <= 4 and bool((holds[1:] > holds[:-1]).any())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("env_name", ENV_NAMES)
+def test_update_ref_kernel_matches_the_host_twin(env_name, dtype):
+    """excenv_update_ref (threefry split / uniform / randint / ball in one launch) against the torch restatement in
+    random.py + GymWrapper.generate_new_ref on the same keys: keys and hold counters bit for bit, references bit for bit for
+    the uniform-drawn environments and to libm accuracy for PMSM's ball-drawn currents."""
+    from exciting_environments_amd import GymWrapper, _native
+    from exciting_environments_amd import random as jr
+
+    B = 4096
+    env, props, keep, spec = make_env(env_name, B, dtype)
+    cs = CONTROL[env_name]
+    gw = GymWrapper(env=env, control_state=cs, ref_params={"hold_steps_min": 10, "hold_steps_max": 1000})
+    gw.device_update_ref = False
+    keys = jr.split(jr.PRNGKey(77, device=env.device), B)
+    _, state = env.vmap_reset()
+    import dataclasses
+    refs0 = {n: torch.full((B,), 0.25, dtype=dtype, device=env.device) for n in cs}
+    state = dataclasses.replace(state, PRNGKey=keys, reference=env.PhysicalState(
+        **{n: refs0.get(n, getattr(state.reference, n)) for n in env.STATE_FIELDS}))
+    hold = torch.as_tensor(np.random.default_rng(1).integers(0, 3, (B, 1)), device=env.device)  # about a third are due
+    want_state, want_hold = gw.update_ref(state, hold)
+    new_refs = [refs0[n].clone() for n in cs]
+    k2, h2 = keys.clone(), hold.reshape(B).clone()
+    p, _k = env._props_for(env.env_properties, B)
+    _native.update_ref(env.ENV_ID, dtype, B, p, [env.STATE_FIELDS.index(n) for n in cs], new_refs, k2, h2, 10, 1000)
+    assert torch.equal(h2, want_hold.reshape(B)) and torch.equal(k2, want_state.PRNGKey)
+    due = hold.reshape(B) == 0
+    assert 0.2 < float(due.float().mean()) < 0.5 and int(h2[due].min()) >= 9 and int(h2[due].max()) < 999
+    for n, got in zip(cs, new_refs):
+        want = getattr(want_state.reference, n)
+        assert torch.equal(got[~due], refs0[n][~due])
+        if env_name == "pmsm":
+            tol = 1e-9 if dtype == torch.float64 else 2e-5
+            close = torch.isclose(got, want, rtol=tol, atol=tol * 250)
+            assert float(close.float().mean()) > 0.999, n  # a rejection decided differently by one ulp changes the sample
+        else:
+            assert torch.equal(got, want), n
