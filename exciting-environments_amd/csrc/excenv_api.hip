@@ -309,6 +309,17 @@ int excenv_update_ref(int env, int dtype, int64_t B, const excenv_props_t* props
   return t->update_ref(rc);
 }
 
+int excenv_random_state(int env, int dtype, int64_t B, const excenv_props_t* props, const int64_t* keys,
+                        void* const* state_out, int64_t* key_leaf, void* stream) {
+  if (int rc = check_common("excenv_random_state", env, 0, dtype, B)) return rc;
+  if (!props || !keys || !state_out || !key_leaf) { set_error("excenv_random_state: NULL argument"); return EXCENV_ENULL; }
+  int trc;
+  const EnvVTable* t = table_for(env, props, &trc);
+  if (!t) return trc;
+  RandomStateCall rc{dtype, B, props, keys, state_out, key_leaf, (hipStream_t)stream};
+  return t->random_state(rc);
+}
+
 int excenv_probe_math(int which, int dtype, int64_t n, const void* in, void* out, void* stream) {
   if (which < 0 || which > 2 || n < 0 || (dtype != EXCENV_F32 && dtype != EXCENV_F64)) { set_error("excenv_probe_math: bad argument"); return EXCENV_EINVAL; }
   if (!in || !out) { set_error("excenv_probe_math: NULL argument"); return EXCENV_ENULL; }

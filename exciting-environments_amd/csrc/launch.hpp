@@ -101,6 +101,16 @@ struct RefGenCall {
   hipStream_t stream;
 };
 
+struct RandomStateCall {
+  int dtype;
+  int64_t B;
+  const excenv_props_t* props;
+  const int64_t* keys;
+  void* const* state_out;
+  int64_t* key_leaf;
+  hipStream_t stream;
+};
+
 struct EnvVTable {
   int S, A, O, P;
   int (*step)(const StepCall&);
@@ -108,6 +118,7 @@ struct EnvVTable {
   int (*traj_gym)(const TrajGymCall&);
   int (*from_obs)(const FromObsCall&);
   int (*update_ref)(const RefGenCall&);
+  int (*random_state)(const RandomStateCall&);
 };
 
 template <typename T, class M>
@@ -531,6 +542,22 @@ template <class M, typename T> static int launch_update_ref(const RefGenCall& rc
   return check_launch("excenv_update_ref");
 }
 
+template <class M, typename T> static int launch_random_state(const RandomStateCall& rc) {
+  RandomStateArgs<T, M> ka;
+  std::memset(&ka, 0, sizeof(ka));
+  fill_props<T, M>(ka.kp, rc.props);
+  ka.B = rc.B;
+  ka.keys = rc.keys;
+  ka.key_leaf = rc.key_leaf;
+  for (int j = 0; j < M::S; ++j) {
+    if (!rc.state_out[j]) { set_error("excenv_random_state: state_out pointer %d is NULL", j); return EXCENV_ENULL; }
+    ka.state_out[j] = (T*)rc.state_out[j];
+  }
+  if (rc.B == 0) return EXCENV_OK;
+  hipLaunchKernelGGL((random_state_kernel<M, T>), dim3((unsigned)((rc.B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, rc.stream, ka);
+  return check_launch("excenv_random_state");
+}
+
 template <template <typename> class MT> struct EnvEntry {
   static int step(const StepCall& sc) {
     return sc.dtype == EXCENV_F32 ? launch_step<MT<float>, float>(sc) : launch_step<MT<double>, double>(sc);
@@ -547,8 +574,12 @@ template <template <typename> class MT> struct EnvEntry {
   static int update_ref(const RefGenCall& rc) {
     return rc.dtype == EXCENV_F32 ? launch_update_ref<MT<float>, float>(rc) : launch_update_ref<MT<double>, double>(rc);
   }
+  static int random_state(const RandomStateCall& rc) {
+    return rc.dtype == EXCENV_F32 ? launch_random_state<MT<float>, float>(rc) : launch_random_state<MT<double>, double>(rc);
+  }
   static EnvVTable vtable() {
-    return EnvVTable{MT<float>::S, MT<float>::A, MT<float>::O, MT<float>::P, &step, &sim, &traj_gym, &from_obs, &update_ref};
+    return EnvVTable{MT<float>::S, MT<float>::A, MT<float>::O, MT<float>::P, &step, &sim, &traj_gym, &from_obs, &update_ref,
+                     &random_state};
   }
 };
 

@@ -145,6 +145,40 @@ template <typename T> __device__ void rng_ball2(Key key, T (&out)[2]) {
   out[1] = g[1] / nrm;
 }
 
+// init_state(key) of one environment (e.g. pendulum_env.py:270-276; PMSM pmsm_env.py:402-456): physical state + the key
+// that becomes the state's PRNGKey leaf.
+template <class M, typename T> __device__ __forceinline__ void init_state_from_key(Key key, const Ctx<T, M>& c, T (&phys)[M::S], Key& leaf) {
+  constexpr int S = M::S;
+  if constexpr (M::IS_PMSM) {
+    const Key s1a = rng_split(key, 0), s1b = rng_split(key, 1);
+    const T sn0 = rng_uniform(s1b, 0, T(-1), T(1)), sn1 = rng_uniform(s1b, 1, T(-1), T(1));
+    const Key s2b = rng_split(s1a, 1);
+    leaf = rng_split(s1a, 0);
+    T disc[2];
+    rng_ball2<T>(s2b, disc);
+    T i_max = xabs(c.smin[3]);
+    i_max = (xabs(c.smax[3]) > i_max) ? xabs(c.smax[3]) : i_max;
+    i_max = (xabs(c.smin[4]) > i_max) ? xabs(c.smin[4]) : i_max;
+    i_max = (xabs(c.smax[4]) > i_max) ? xabs(c.smax[4]) : i_max;
+    auto relu = [](T x) { return (x > T(0)) ? x : T(0); };
+    const T xd = disc[0] * i_max, xq = disc[1] * i_max;
+    const T i_d = xd - T(2) * relu(xd - c.smax[3]) + T(2) * relu(-xd + c.smin[3]);
+    const T i_q = xq - T(2) * relu(xq - c.smax[4]) + T(2) * relu(-xq + c.smin[4]);
+    phys[0] = T(0);
+    phys[1] = T(0);
+    phys[2] = (sn0 + T(1)) / T(2) * (c.smax[2] - c.smin[2]) + c.smin[2];
+    phys[3] = i_d;
+    phys[4] = i_q;
+    phys[5] = M::torque(i_d, i_q, c);
+    phys[6] = (sn1 + T(1)) / T(2) * (c.smax[6] - c.smin[6]) + c.smin[6];
+  } else {  // uniform(key, (S,), -1 (tank: 0), 1) denormalised; PRNGKey leaf = split(key)[1]
+    const T lo = (M::ID == EXCENV_FLUID_TANK) ? T(0) : T(-1);
+#pragma unroll
+    for (int j = 0; j < S; ++j) phys[j] = denormalize(rng_uniform(key, j, lo, T(1)), c.smin[j], c.smax[j]);
+    leaf = rng_split(key, 1);
+  }
+}
+
 template <typename T, class M> struct RefGenArgs {
   KProps<T, M> kp;
   int64_t B;
@@ -167,34 +201,7 @@ template <class M, typename T> __global__ void __launch_bounds__(BLOCK) update_r
     Key key{(uint32_t)ka.keys[2 * i], (uint32_t)ka.keys[2 * i + 1]};
     T phys[S];
     Key leaf;
-    if constexpr (M::IS_PMSM) {  // pmsm_env.py:402-456
-      const Key s1a = rng_split(key, 0), s1b = rng_split(key, 1);
-      const T sn0 = rng_uniform(s1b, 0, T(-1), T(1)), sn1 = rng_uniform(s1b, 1, T(-1), T(1));
-      const Key s2b = rng_split(s1a, 1);
-      leaf = rng_split(s1a, 0);
-      T disc[2];
-      rng_ball2<T>(s2b, disc);
-      T i_max = xabs(c.smin[3]);
-      i_max = (xabs(c.smax[3]) > i_max) ? xabs(c.smax[3]) : i_max;
-      i_max = (xabs(c.smin[4]) > i_max) ? xabs(c.smin[4]) : i_max;
-      i_max = (xabs(c.smax[4]) > i_max) ? xabs(c.smax[4]) : i_max;
-      auto relu = [](T x) { return (x > T(0)) ? x : T(0); };
-      const T xd = disc[0] * i_max, xq = disc[1] * i_max;
-      const T i_d = xd - T(2) * relu(xd - c.smax[3]) + T(2) * relu(-xd + c.smin[3]);
-      const T i_q = xq - T(2) * relu(xq - c.smax[4]) + T(2) * relu(-xq + c.smin[4]);
-      phys[0] = T(0);
-      phys[1] = T(0);
-      phys[2] = (sn0 + T(1)) / T(2) * (c.smax[2] - c.smin[2]) + c.smin[2];
-      phys[3] = i_d;
-      phys[4] = i_q;
-      phys[5] = M::torque(i_d, i_q, c);
-      phys[6] = (sn1 + T(1)) / T(2) * (c.smax[6] - c.smin[6]) + c.smin[6];
-    } else {  // uniform(key, (S,), -1 (tank: 0), 1) denormalised; PRNGKey leaf = split(key)[1]
-      const T lo = (M::ID == EXCENV_FLUID_TANK) ? T(0) : T(-1);
-#pragma unroll
-      for (int j = 0; j < S; ++j) phys[j] = denormalize(rng_uniform(key, j, lo, T(1)), c.smin[j], c.smax[j]);
-      leaf = rng_split(key, 1);
-    }
+    init_state_from_key<M, T>(key, c, phys, leaf);
 #pragma unroll
     for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
       if (j < ka.n_control) {
@@ -211,6 +218,30 @@ template <class M, typename T> __global__ void __launch_bounds__(BLOCK) update_r
     ka.keys[2 * i + 1] = (int64_t)k_new.k1;
   }
   ka.hold[i] = h - 1;
+}
+
+// CoreEnvironment.vmap_init_state(rng) with one key per environment: physical state leaves + PRNGKey leaf
+template <typename T, class M> struct RandomStateArgs {
+  KProps<T, M> kp;
+  int64_t B;
+  const int64_t* keys;  // [B][2]
+  T* state_out[M::S];
+  int64_t* key_leaf;    // [B][2]
+};
+
+template <class M, typename T> __global__ void __launch_bounds__(BLOCK) random_state_kernel(const RandomStateArgs<T, M> ka) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= ka.B) return;
+  Ctx<T, M> c;
+  load_ctx<true, T, M, false>(c, ka.kp, i, T(0), T(0), T(0));
+  const Key key{(uint32_t)ka.keys[2 * i], (uint32_t)ka.keys[2 * i + 1]};
+  T phys[M::S];
+  Key leaf;
+  init_state_from_key<M, T>(key, c, phys, leaf);
+#pragma unroll
+  for (int j = 0; j < M::S; ++j) ka.state_out[j][i] = phys[j];
+  ka.key_leaf[2 * i] = (int64_t)leaf.k0;
+  ka.key_leaf[2 * i + 1] = (int64_t)leaf.k1;
 }
 
 }  // namespace excenv

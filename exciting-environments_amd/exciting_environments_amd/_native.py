@@ -91,7 +91,7 @@ def lib():
         l.excenv_truncated_width.restype = ctypes.c_int32
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
                    "excenv_probe_math", "excenv_probe_div", "excenv_rew_trunc_term", "excenv_state_from_observation",
-                   "excenv_update_ref"):
+                   "excenv_update_ref", "excenv_random_state"):
             getattr(l, fn).restype = ctypes.c_int
         vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
         # typed prototypes: plain Python ints / floats / None / byref() pass without per-call ctypes wrapping
@@ -317,6 +317,18 @@ def update_ref(env_id, dtype, B, props: Props, control_idx: Sequence[int], refer
             ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(hold.data_ptr()), ctypes.c_int32(hold_min), ctypes.c_int32(hold_max),
             ctypes.c_void_p(_raw_stream(keys.device)))
     _check(rc, "excenv_update_ref")
+
+
+def random_state(env_id, dtype, B, props: Props, keys: torch.Tensor, state_out: Sequence[torch.Tensor], key_leaf: torch.Tensor):
+    """excenv_random_state: init_state(key) for every environment in one launch (keys / key_leaf: int64 [B, 2])."""
+    _require_device(keys, "vmap_init_state")
+    assert keys.dtype == torch.int64 and keys.is_contiguous() and key_leaf.dtype == torch.int64 and key_leaf.is_contiguous()
+    with _on_device(keys.device):
+        rc = lib().excenv_random_state(
+            ctypes.c_int(env_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B), ctypes.byref(props),
+            ctypes.c_void_p(keys.data_ptr()), _ptrs(state_out), ctypes.c_void_p(key_leaf.data_ptr()),
+            ctypes.c_void_p(_raw_stream(keys.device)))
+    _check(rc, "excenv_random_state")
 
 
 def sim_ahead_workspace_bytes(env_id, dtype, B, K, substeps, n_control, action_layout, traj_layout,

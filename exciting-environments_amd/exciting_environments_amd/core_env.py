@@ -274,7 +274,33 @@ class CoreEnvironment(ABC):
             for n in self.STATE_FIELDS
         }
 
+    def _init_state_device_keys(self, env_properties, rng, shape):
+        """One launch (excenv_random_state) for a [B, 2] batch of keys on the HIP device; None when this path does not apply
+        (CPU, single key, property arrays of another batch size) and the torch twin has to do it."""
+        if not (_random.is_key(rng) and len(shape) == 1 and rng.ndim == 2 and self.device.type == "cuda"):
+            return None
+        B = shape[0]
+        assert tuple(rng.shape) == (B, 2), f"rng keys must have shape {(B, 2)}"
+        try:
+            props, _keep = self._props_for(env_properties, B)
+        except ValueError:
+            return None
+        S = self.physical_state_dim
+        al = 16 // (4 if self.dtype == torch.float32 else 8)
+        Bp = (B + al - 1) // al * al
+        buf = torch.empty((S, Bp), dtype=self.dtype, device=self.device)
+        leaves = [buf[j, :B] for j in range(S)]
+        keys = rng.to(device=self.device, dtype=torch.int64).contiguous()
+        leaf = torch.empty_like(keys)
+        _native.random_state(self.ENV_ID, self.dtype, B, props, keys, leaves, leaf)
+        ref = {n: self._nan(shape) for n in self.STATE_FIELDS}
+        return self.State(physical_state=self.PhysicalState(*leaves), PRNGKey=leaf, additions=self._additions(shape, False),
+                          reference=self.PhysicalState(**ref))
+
     def _init_state(self, env_properties, rng, shape):
+        dev = self._init_state_device_keys(env_properties, rng, shape)
+        if dev is not None:
+            return dev
         if rng is None:
             norm = {n: torch.full(shape, v, dtype=self.dtype, device=self.device)
                     for n, v in zip(self.STATE_FIELDS, self.DEFAULT_NORM_STATE)}

@@ -357,6 +357,9 @@ class PMSM(CoreEnvironment):
 
     def _init_state(self, env_properties, rng, shape):
         """pmsm_env.py:383-485: physical units directly (no denormalisation pass)."""
+        dev = self._init_state_device_keys(env_properties, rng, shape)
+        if dev is not None:
+            return dev
         pn = env_properties.physical_normalizations
         full = lambda v: torch.as_tensor(v, dtype=self.dtype, device=self.device).expand(shape).clone()
         lo_hi = lambda n: (self._norm_leaf(getattr(pn, n).min), self._norm_leaf(getattr(pn, n).max))

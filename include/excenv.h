@@ -250,6 +250,12 @@ int excenv_update_ref(int env, int dtype, int64_t B, const excenv_props_t* props
                       const int32_t* control_idx, void* const* reference, int64_t* keys, int64_t* hold,
                       int32_t hold_steps_min, int32_t hold_steps_max, void* stream);
 
+/* ---- replaces CoreEnvironment.vmap_init_state(rng) (core_env.py:649-662) with one key per environment: the random branch
+ * of each environment's init_state (e.g. pendulum_env.py:270-276, PMSM pmsm_env.py:402-456) — state_out[S][B] physical state
+ * leaves, key_leaf [B][2] the keys that become State.PRNGKey. Same samplers as excenv_update_ref. */
+int excenv_random_state(int env, int dtype, int64_t B, const excenv_props_t* props, const int64_t* keys,
+                        void* const* state_out, int64_t* key_leaf, void* stream);
+
 /* ---- device-math probes (tests only): out[i] = f(in[i]) for the in-kernel fp32 routines -- */
 int excenv_probe_math(int which /*0 sin,1 cos,2 wrap_angle*/, int dtype, int64_t n,
                       const void* in, void* out, void* stream);
