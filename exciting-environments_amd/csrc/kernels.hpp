@@ -315,7 +315,12 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
 // the row of solver step n+1 is requested before row n is saved and step n is computed, and is first read one whole step
 // later (Euler) or in the last RK stage of step n (c_i == 1 stages see action k+1) — its s_waitcnt therefore sits after a
 // compute phase and never has to drain the trajectory stores issued in between (vmcnt counts loads and stores in order).
-template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V>
+//
+// STATES: the state trajectories are written (1), not written (0), or decided by ka.straj[0] at run time (-1, GENERAL only).
+// It is a compile-time property on the vectorised instantiations because s_waitcnt vmcnt counts loads and stores in issue
+// order: with the state stores behind a run-time branch the compiler must assume the shorter path, and the wait for the
+// prefetched action row then also waits for the first seven stores of the row just written.
+template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES>
 __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
   static_assert(!(GENERAL && V > 1), "vectorised lanes share one uniform property set");
@@ -375,7 +380,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   const unsigned a_lane = (V == 1) ? threadIdx.x * (unsigned)ka.a_sb : lane_env;
   const unsigned o_lane = (V == 1) ? threadIdx.x * (unsigned)ka.o_sb : lane_env;
   const unsigned s_lane = (V == 1) ? threadIdx.x * (unsigned)ka.s_sb : lane_env;
-  const bool with_states = ka.straj[0] != nullptr;
+  const bool with_states = (STATES < 0) ? (ka.straj[0] != nullptr) : (STATES != 0);
 
   // ---- save row n: observation, (control columns), state leaves, (gym outputs); returns the saved state in sv ----
   auto save_row = [&](int64_t n, T (&sv)[V][S]) {

@@ -294,14 +294,19 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
   if (general) {
-    EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, true, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
+    EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, true, 1, -1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
+    return;
+  }
+  constexpr int VMAX = 16 / (int)sizeof(T);
+  if (ka.straj[0] == nullptr) {  // observations only: instantiated for the widest lanes (launch_sim routes the rest to `general`)
+    EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VMAX, 0>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
     return;
   }
   if constexpr (sizeof(T) == 4) {
-    if (V == 4) { EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 4>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); return; }
+    if (V == 4) { EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 4, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); return; }
   }
-  if (V == 2) { EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 2>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); return; }
-  EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
+  if (V == 2) { EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 2, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); return; }
+  EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 1, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
 }
 
 template <class M, typename T> static int launch_sim(const SimCall& sc) {
@@ -321,7 +326,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   const int64_t N = sc.K * sc.substeps;
   const int64_t OW = M::O + ka.n_control;
   const bool with_gym = sc.gym != nullptr;
-  const bool general = batched || ka.n_control > 0 || with_gym;
+  bool general = batched || ka.n_control > 0 || with_gym;
   bool vec_ok = !general;
   for (int j = 0; j < M::S; ++j) {
     if (!sc.state_in[j] || !sc.last_state[j]) { set_error("excenv_sim_ahead: state pointer %d is NULL", j); return EXCENV_ENULL; }
@@ -431,6 +436,10 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     } else {
       V = VT;
     }
+  }
+  if (!general && ka.straj[0] == nullptr && V != VMAX) {  // observations only exists for the widest lanes and in the general kernel
+    general = true;
+    V = 1;
   }
   {  // element offset of workgroup w's first env in each stream
     const int64_t wg_envs = (int64_t)BLOCK * V;

@@ -43,9 +43,12 @@ template <> struct Tableau<EXCENV_TSIT5> {
   __host__ __device__ static constexpr bool c_is_one(int s) { return s == 5; }
 };
 
-// u: action held over the step; u1: action seen by stages with c_i == 1 (== u on the step path).
-template <class M, int SOLVER, typename T>
-__device__ __forceinline__ void rk_step(T (&y)[M::NY], const T (&u)[M::A], const T (&u1)[M::A], const Ctx<T, M>& c,
+// u: action held over the step; u1_of(u1): fills the action seen by stages with c_i == 1 (== u on the step path). It is a
+// callable evaluated AT that stage: on the sim_ahead path it reads the prefetched next action row, and the s_waitcnt for that
+// load sits in front of the first instruction that touches those registers — evaluated up front, every solver step would
+// start by waiting for a load issued a few hundred instructions earlier.
+template <class M, int SOLVER, typename T, class U1>
+__device__ __forceinline__ void rk_step(T (&y)[M::NY], const T (&u)[M::A], U1&& u1_of, const Ctx<T, M>& c,
                                         const T (&st)[M::S]) {
   constexpr int NY = M::NY;
   T dy[NY];
@@ -69,10 +72,13 @@ __device__ __forceinline__ void rk_step(T (&y)[M::NY], const T (&u)[M::A], const
         }
         yi[j] = (s == 0) ? y[j] : y[j] + acc;
       }
-      if (TB::c_is_one(s))
+      if (TB::c_is_one(s)) {
+        T u1[M::A];
+        u1_of(u1);
         M::f(yi, u1, c, st, dy);
-      else
+      } else {
         M::f(yi, u, c, st, dy);
+      }
 #pragma unroll
       for (int j = 0; j < NY; ++j) k[s][j] = dy[j] * c.dt;
     }
@@ -107,7 +113,10 @@ __device__ __forceinline__ void env_step(T (&st)[M::S], const T (&a)[M::A], cons
   }
   T y[M::NY];
   M::get_y(st, y);
-  rk_step<M, SOLVER>(y, u, u, c, st);
+  rk_step<M, SOLVER>(y, u, [&](T (&u1)[M::A]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < M::A; ++q) u1[q] = u[q];
+  }, c, st);
   M::set_y(st, y);
   M::post(st, c);
 }
@@ -123,31 +132,35 @@ template <typename T> struct AheadAux {
 template <class M, int SOLVER, typename T>
 __device__ __forceinline__ void env_advance_raw(T (&st)[M::S], const T (&a)[M::A], const T (&a1)[M::A], int64_t k,
                                                 int64_t k1, const Ctx<T, M>& c, AheadAux<T>& aux) {
-  T u[M::A], u1[M::A];
+  T u[M::A];
+  T uc[2] = {T(0), T(0)};
+  bool dead = false;
   if constexpr (M::IS_PMSM) {
-    T uc[2];
     M::constraint(a, aux.eps0 + (T(k) * c.env_tau) * st[6], st[6], c, uc);
-    if (c.P[6] > T(0)) {
-      u[0] = aux.prev_clip[0]; u[1] = aux.prev_clip[1];
-      u1[0] = (k1 == k) ? u[0] : uc[0];
-      u1[1] = (k1 == k) ? u[1] : uc[1];
-    } else {
-      u[0] = uc[0]; u[1] = uc[1];
-      if constexpr (SOLVER != EXCENV_EULER) {
-        M::constraint(a1, aux.eps0 + (T(k1) * c.env_tau) * st[6], st[6], c, u1);
-      } else {
-        u1[0] = u[0]; u1[1] = u[1];
-      }
-    }
+    dead = c.P[6] > T(0);
+    u[0] = dead ? aux.prev_clip[0] : uc[0];
+    u[1] = dead ? aux.prev_clip[1] : uc[1];
     aux.prev_clip[0] = uc[0];
     aux.prev_clip[1] = uc[1];
   } else {
     u[0] = denormalize(a[0], c.amin[0], c.amax[0]);
-    u1[0] = denormalize(a1[0], c.amin[0], c.amax[0]);
   }
+  // the action of stages with c_i == 1: row k1 (== k inside an action's sub-steps), read only when that stage is reached
+  auto u1_of = [&](T (&u1)[M::A]) __attribute__((always_inline)) {
+    if constexpr (M::IS_PMSM) {
+      if (dead) {
+        u1[0] = (k1 == k) ? u[0] : uc[0];
+        u1[1] = (k1 == k) ? u[1] : uc[1];
+      } else {
+        M::constraint(a1, aux.eps0 + (T(k1) * c.env_tau) * st[6], st[6], c, u1);
+      }
+    } else {
+      u1[0] = denormalize(a1[0], c.amin[0], c.amax[0]);
+    }
+  };
   T y[M::NY];
   M::get_y(st, y);
-  rk_step<M, SOLVER>(y, u, u1, c, st);
+  rk_step<M, SOLVER>(y, u, u1_of, c, st);
   M::set_y(st, y);
 }
 
