@@ -518,11 +518,18 @@ def test_entry_points_are_hip_graph_capturable():
 
 # ------------------------------------------------------------------------------------------------ device math
 def test_device_sincos_fp32_within_2ulp():
+    """The in-kernel fp32 sin / cos (devmath.hpp sincos_t). Wrapped angles and a few turns (what the step path sees):
+    <= 2 ulp, or <= 4e-9 absolute next to a zero. The whole fast-path range |x| <= 65536 (raw sim_ahead angles grow with
+    the trajectory): <= 1e-7 absolute, zeros of sin / cos included; beyond it the device library is exact again."""
     from exciting_environments_amd import _native
 
     x = torch.cat([torch.linspace(-3.1415927, 3.1415927, 2_000_001), torch.linspace(-50, 50, 500_001),
-                   torch.tensor([0.0, -0.0, 1e-30, -1e-20, 3.1415927, -3.1415927, 1.5707964, 1000.0, 1e6, 1e10])]
+                   torch.tensor([0.0, -0.0, 1e-30, -1e-20, 3.1415927, -3.1415927, 1.5707964, 1e6, 1e10])]
                   ).to(torch.float32).cuda()
+    k = (torch.arange(-40000, 40001, dtype=torch.float64) * (np.pi / 2)).to(torch.float32)
+    wide = torch.cat([torch.linspace(-65536.0, 65536.0, 2_000_001), torch.linspace(-70000.0, 70000.0, 200_001), k,
+                      torch.nextafter(k, torch.tensor(1e9)), torch.nextafter(k, torch.tensor(-1e9)),
+                      torch.tensor([1000.0, 65536.0, 65537.0, -65536.0])]).to(torch.float32).cuda()
     for which, fn in ((0, np.sin), (1, np.cos)):
         got = _native.probe_math(which, x).cpu().numpy().astype(np.float64)
         want = fn(x.cpu().numpy().astype(np.float64))
@@ -531,6 +538,9 @@ def test_device_sincos_fp32_within_2ulp():
         # near the zeros of sin/cos the reduction's absolute error (~1e-9) dominates the shrinking ulp
         ok = (err <= 2.0) | (np.abs(got - want) <= 4e-9)
         assert ok.all(), (which, float(err[~ok].max()))
+        got = _native.probe_math(which, wide).cpu().numpy().astype(np.float64)
+        want = fn(wide.cpu().numpy().astype(np.float64))
+        assert float(np.abs(got - want).max()) <= 1.0e-7, (which, float(np.abs(got - want).max()))
 
 
 def test_device_wrap_angle_is_python_modulo_bit_exact():
