@@ -160,12 +160,16 @@ def ptr_array(addresses: Sequence[int]):
 _get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+def raw_stream(device_index: int) -> int:
+    """The current HIP stream of the (current) device as an integer handle."""
+    return _get_raw_stream(device_index) if _get_raw_stream is not None else torch.cuda.current_stream().cuda_stream
+
+
 def step_raw(env_id, solver_id, dtype_code, B, props_ref, control_ref, tau, in_ptrs, action_ptr, out_ptrs, obs_ptr, opts_ref,
-             device_index, gym=None):
+             stream, gym=None):
     """excenv_step / excenv_gym_step with every argument already in its C form (pointer arrays and byref()s cached by the
-    caller). `gym` = (reward_ptr, terminated_ptr, truncated_ptr) selects excenv_gym_step. The caller guarantees that
-    `device_index` is the current device."""
-    stream = _get_raw_stream(device_index) if _get_raw_stream is not None else torch.cuda.current_stream().cuda_stream
+    caller). `gym` = (reward_ptr, terminated_ptr, truncated_ptr) selects excenv_gym_step. `stream` = raw_stream() of the
+    device the buffers live on, which the caller has made current."""
     if gym is None:
         rc = _lib.excenv_step(env_id, solver_id, dtype_code, B, props_ref, control_ref, tau, in_ptrs, action_ptr, out_ptrs,
                               obs_ptr, opts_ref, stream)

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import sys
 import warnings
 from abc import ABC
 from dataclasses import dataclass, fields, is_dataclass, replace
@@ -449,9 +450,20 @@ class CoreEnvironment(ABC):
     # a few microseconds, so the host side decides the rate. Per call this path does: identity check of the incoming state
     # leaves (did we return them last time? then their pointer array is already built), one data_ptr() for the action, one
     # ctypes call with pre-built arguments, two small dataclass constructions. Outputs are still fresh memory every call
-    # (functional contract): slots are carved from one allocation per `n` calls and never reused.
+    # (functional contract): slots are carved from one allocation per `n` calls. Once a pool is used up its oldest slot is
+    # handed out again ONLY if nothing outside this object can still see it — no Python reference to any of its tensors or
+    # to its PhysicalState (sys.getrefcount back at the value recorded when the pool was made), no C++ holder of a tensor
+    # (Tensor._use_count() == 1: autograd, DLPack, views keep their base), no foreign view on the pool's storage (storage
+    # use count back at its recorded value) and the same stream as before (the kernels that read the slot are then ordered
+    # before the one that overwrites it). In `obs, state = env.vmap_step(state, act)` the outputs of two calls ago are dead,
+    # so the loop runs on recycled tensor objects: creating the S + 1 views per call was the largest item of the host time.
+    # Anything still referenced makes the test fail and a new pool is allocated, as before.
     class _Slots:
-        __slots__ = ("n", "i", "leaves", "obs", "out_ptrs", "obs_ptrs", "gym", "gym_ptrs")
+        __slots__ = ("n", "i", "leaves", "obs", "out_ptrs", "obs_ptrs", "gym", "gym_ptrs", "phys", "objs", "tens", "rc0",
+                     "storages", "use0", "stream", "obs_width")
+
+    _storage_use_count = getattr(torch._C, "_storage_Use_Count", None)
+    _tensor_use_count = getattr(torch.Tensor, "_use_count", None)
 
     def _new_slots(self, n: int, gym: bool):
         B, S, O = self.batch_size, self.physical_state_dim, self._obs_dim()
@@ -480,7 +492,32 @@ class CoreEnvironment(ABC):
             sl.gym = list(zip(rew, term, trunc))
             sl.gym_ptrs = [(base + (i * slot + S * Bp + obs_elems) * isz, fbase + i * B * (1 + TW),
                             fbase + i * B * (1 + TW) + B) for i in range(n)]
+        # recycling bookkeeping (see the comment above _Slots)
+        sl.obs_width = O
+        sl.phys = [self.PhysicalState(*lv) for lv in sl.leaves]
+        sl.tens = [tuple(sl.leaves[i]) + (sl.obs[i],) + (tuple(sl.gym[i]) if gym else ()) for i in range(n)]
+        sl.objs = [sl.tens[i] + (sl.phys[i],) for i in range(n)]
+        sl.storages = [buf.untyped_storage()] + ([flags.untyped_storage()] if gym else [])
+        sl.rc0 = sl.use0 = sl.stream = None
         return sl
+
+    def _slot_is_free(self, sl, i: int, stream) -> bool:
+        if sl.rc0 is None or sl.stream != stream:
+            return False
+        if tuple(map(sys.getrefcount, sl.objs[i])) != sl.rc0[i]:
+            return False
+        tens = sl.tens[i]
+        if sum(map(CoreEnvironment._tensor_use_count, tens)) != len(tens):
+            return False
+        return [CoreEnvironment._storage_use_count(st._cdata) for st in sl.storages] == sl.use0
+
+    def _arm_recycling(self, sl, stream):
+        """Record the reference counts of a fresh pool (nothing outside `sl` refers to its tensors yet)."""
+        if CoreEnvironment._storage_use_count is None or CoreEnvironment._tensor_use_count is None:
+            return  # this torch build cannot tell whether a slot is still visible: never recycle
+        sl.stream = stream
+        sl.rc0 = [tuple(map(sys.getrefcount, o)) for o in sl.objs]
+        sl.use0 = [CoreEnvironment._storage_use_count(st._cdata) for st in sl.storages]
 
     def _slots_per_alloc(self, gym: bool) -> int:
         isz = 4 if self.dtype == torch.float32 else 8
@@ -522,23 +559,38 @@ class CoreEnvironment(ABC):
                 cc = self._ctl_cache = (key, (refs, obs_refs), (tens, otens), ctl, ctypes.byref(ctl))
             control_ref = cc[4]
         props, _keep = self._props_for(self.env_properties, B)
-        capturing = torch._C._cuda_isCurrentStreamCapturing()
-        sl = None if capturing else self._slots[gym]
-        if sl is None or sl.i == sl.n or sl.obs[0].shape[1] != (self._obs_dim_cache[1] if self._obs_dim_cache and
-                                                                 self._obs_dim_cache[0] == len(self.control_state) else self._obs_dim()):
-            sl = self._new_slots(1 if capturing else self._slots_per_alloc(gym), gym)
-            if not capturing:  # memory allocated during capture belongs to the graph's pool: never handed out later
-                self._slots[gym] = sl
-        i = sl.i
-        sl.i = i + 1
-        opts = self.launch_opts
         idx = dev.index
         cur = torch._C._cuda_getDevice()
         if idx is None:
             idx = cur
+        if idx == cur:
+            stream = _native.raw_stream(idx)
+            capturing = torch._C._cuda_isCurrentStreamCapturing()
+        else:
+            with torch.cuda.device(dev):
+                stream = _native.raw_stream(idx)
+                capturing = torch._C._cuda_isCurrentStreamCapturing()
+        sl = None if capturing else self._slots[gym]
+        if sl is not None:
+            i = sl.i
+            if i >= sl.n:  # pool used up: its oldest slot again, if nothing can see that slot's tensors any more
+                i %= sl.n
+                if not self._slot_is_free(sl, i, stream):
+                    sl = None
+            if sl is not None and sl.obs_width != (self._obs_dim_cache[1] if self._obs_dim_cache and self._obs_dim_cache[0]
+                                                   == len(self.control_state) else self._obs_dim()):
+                sl = None
+        if sl is None:
+            sl = self._new_slots(1 if capturing else self._slots_per_alloc(gym), gym)
+            i = 0
+            if not capturing:  # memory allocated during capture belongs to the graph's pool: never handed out later
+                self._slots[gym] = sl
+                self._arm_recycling(sl, stream)
+        sl.i += 1
+        opts = self.launch_opts
         args = (self.ENV_ID, self._solver.id, 0 if self.dtype is torch.float32 else 1, B, ctypes.byref(props), control_ref,
                 self.tau, in_ptrs, action.data_ptr(), sl.out_ptrs[i], sl.obs_ptrs[i],
-                None if opts is None else ctypes.byref(opts), idx, sl.gym_ptrs[i] if gym else None)
+                None if opts is None else ctypes.byref(opts), stream, sl.gym_ptrs[i] if gym else None)
         if idx == cur:
             _native.step_raw(*args)
         else:
@@ -550,7 +602,7 @@ class CoreEnvironment(ABC):
         add = self._active_additions
         if add is None:
             add = self._active_additions = self._additions((B,), True)
-        new_state = self.State(self.PhysicalState(*new_leaves), state.PRNGKey, add, state.reference)
+        new_state = self.State(sl.phys[i], state.PRNGKey, add, state.reference)
         if gym:
             rew, term, trunc = sl.gym[i]
             return sl.obs[i], rew, term, trunc, new_state

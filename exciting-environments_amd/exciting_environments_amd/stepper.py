@@ -104,8 +104,9 @@ class Stepper:
     def _launch_all(self):
         eid, sid, dtc, B, pref, cref, tau, ptrs, oref, idx, per = self._args
         step_raw = _native.step_raw
+        stream = _native.raw_stream(idx)  # once per run: all n_steps launches go to the caller's current stream
         for a_ptr, o_ptr, g in per:
-            step_raw(eid, sid, dtc, B, pref, cref, tau, ptrs, a_ptr, ptrs, o_ptr, oref, idx, g)
+            step_raw(eid, sid, dtc, B, pref, cref, tau, ptrs, a_ptr, ptrs, o_ptr, oref, stream, g)
 
     def run(self):
         """n_steps steps from the current in-place state with `self.actions`; returns (obs [n,B,O], state) — plus
