@@ -105,6 +105,16 @@ __device__ __forceinline__ void load_ctx(Ctx<T, M>& c, const KProps<T, M>& kp, i
   c.lut_nd = kp.lut_nd;
   c.lut_nq = kp.lut_nq;
   c.lut_lds = 0;
+  if constexpr (M::HAS_LUT) {  // wave-uniform: first node and (n - 1) / (last - first) of both grids
+    c.lut_g0[0] = c.lut_g0[1] = c.lut_sc[0] = c.lut_sc[1] = T(0);
+    if (kp.lut_tab != nullptr) {
+      const T d0 = kp.lut_gd[0], dl = kp.lut_gd[kp.lut_nd - 1], q0 = kp.lut_gq[0], ql = kp.lut_gq[kp.lut_nq - 1];
+      c.lut_g0[0] = d0;
+      c.lut_g0[1] = q0;
+      c.lut_sc[0] = T(kp.lut_nd - 1) / (dl - d0);
+      c.lut_sc[1] = T(kp.lut_nq - 1) / (ql - q0);
+    }
+  }
   prep_ctx(c);
 }
 
@@ -121,6 +131,19 @@ __device__ __forceinline__ void stage_lut(Ctx<T, M>& c, const KProps<T, M>& kp) 
       for (int j = threadIdx.x; j < ntab; j += blockDim.x) sm[j] = kp.lut_tab[j];
       for (int j = threadIdx.x; j < kp.lut_nd; j += blockDim.x) sm[ntab + j] = kp.lut_gd[j];
       for (int j = threadIdx.x; j < kp.lut_nq; j += blockDim.x) sm[ntab + kp.lut_nd + j] = kp.lut_gq[j];
+      // refined reciprocals of the cell widths (InvDiv: the interpolation weight keeps the bits of its division)
+      T* rd = sm + ntab + kp.lut_nd + kp.lut_nq;
+      T* rq = rd + kp.lut_nd;
+      for (int j = threadIdx.x; j < kp.lut_nd; j += blockDim.x) {
+        InvDiv<T> w;
+        w.init((j + 1 < kp.lut_nd) ? kp.lut_gd[j + 1] - kp.lut_gd[j] : T(1), true);
+        rd[j] = w.y;
+      }
+      for (int j = threadIdx.x; j < kp.lut_nq; j += blockDim.x) {
+        InvDiv<T> w;
+        w.init((j + 1 < kp.lut_nq) ? kp.lut_gq[j + 1] - kp.lut_gq[j] : T(1), true);
+        rq[j] = w.y;
+      }
       __syncthreads();
       c.lut_lds = 1;
     }
@@ -320,7 +343,10 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
 // It is a compile-time property on the vectorised instantiations because s_waitcnt vmcnt counts loads and stores in issue
 // order: with the state stores behind a run-time branch the compiler must assume the shorter path, and the wait for the
 // prefetched action row then also waits for the first seven stores of the row just written.
-template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES>
+// LUT_LDS (look-up models): the launch staged the tables in LDS (true) or the kernel gathers from global memory (false) —
+// a compile-time property so that each instantiation carries ONE copy of the look-up code (the saturated-PMSM loops are
+// the largest in the library and run out of the 64 KB instruction cache otherwise).
+template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false>
 __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
   static_assert(!(GENERAL && V > 1), "vectorised lanes share one uniform property set");
@@ -330,6 +356,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   Ctx<T, M> c;
   load_ctx<GENERAL>(c, ka.kp, (i0 < ka.B) ? i0 : 0, ka.dt, ka.env_tau, ka.adv_coef);
   stage_lut<M, T>(c, ka.kp);
+  if constexpr (M::HAS_LUT) c.lut_lds = LUT_LDS ? 1 : 0;  // == ka.kp.lut_lds (launch_sim_v picks the instantiation by it)
   if (i0 >= ka.B) return;  // host guarantees B % V == 0
 
   T st[V][S];
@@ -350,6 +377,13 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
     }
   }
   const bool deadtime_on = (M::IS_PMSM) ? (c.P[M::P - 1] > T(0)) : false;
+  // look-up models: the table values at each environment's current operating point, found once per solver step and used
+  // for the torque of the saved row and for the first stage of the step that starts there
+  T memo[V][6];
+  if constexpr (M::HAS_LUT && !AHEAD) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) M::lookup(st[v][3], st[v][4], c, memo[v]);
+  }
 
   // reference-tracking columns: constant along the trajectory, loaded and normalised once (static register indices)
   T rref[EXCENV_MAX_CONTROL], cref[EXCENV_MAX_CONTROL];
@@ -389,7 +423,8 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
 #pragma unroll
       for (int j = 0; j < S; ++j) sv[v][j] = st[v][j];
       if constexpr (AHEAD) {
-        M::post(sv[v], c);
+        if constexpr (M::HAS_LUT) M::post_q(sv[v], c, memo[v]);
+        else M::post(sv[v], c);
         if constexpr (M::IS_PMSM) {  // pmsm_env.py:785-791
           if (deadtime_on) {
             sv[v][0] = (n == 0) ? aux[v].buf0[0] : aux[v].prev_clip[0];
@@ -468,9 +503,9 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
         an[q] = nxt[q][v];
       }
       if constexpr (AHEAD) {
-        env_advance_raw<M, SOLVER>(st[v], ac, an, k, k1, c, aux[v]);
+        env_advance_raw<M, SOLVER>(st[v], ac, an, k, k1, c, aux[v], M::HAS_LUT ? &memo[v] : nullptr);
       } else {
-        env_step<M, SOLVER>(st[v], ac, c);
+        env_step<M, SOLVER>(st[v], ac, c, M::HAS_LUT ? &memo[v] : nullptr);
       }
     }
   };
@@ -484,7 +519,8 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   };
   const int64_t klast = ka.K - 1;
   load_action(0, a0);
-  constexpr bool PINGPONG = ((SOLVER == EXCENV_EULER) ? (EXCENV_PINGPONG & 1) : (EXCENV_PINGPONG & 2)) != 0;
+  // look-up models keep the single-step loop: twice the (large) look-up code does not fit the instruction cache
+  constexpr bool PINGPONG = !M::HAS_LUT && ((SOLVER == EXCENV_EULER) ? (EXCENV_PINGPONG & 1) : (EXCENV_PINGPONG & 2)) != 0;
   if constexpr (PINGPONG) {
     for (int64_t n = 0;; n += 2) {
       // even step: a0 holds action row k; the row of step n + 1 goes to a1 (clamped: always a valid row, so the load is

@@ -169,7 +169,7 @@ static bool fill_props(KProps<T, M>& kp, const excenv_props_t* p) {
 // Dynamic LDS for the saturated model's tables: staged when they fit LDS (<= 150 KiB, leaving room for one workgroup).
 template <typename T, class M> static size_t lut_lds_bytes(KProps<T, M>& kp, size_t other) {
   if constexpr (!M::HAS_LUT) return other;
-  const size_t need = ((size_t)kp.lut_nd * kp.lut_nq * 8 + kp.lut_nd + kp.lut_nq) * sizeof(T);
+  const size_t need = ((size_t)kp.lut_nd * kp.lut_nq * 8 + 2 * (size_t)(kp.lut_nd + kp.lut_nq)) * sizeof(T);  // tables, grids, cell-width reciprocals
   if (kp.lut_tab && need + other <= 150 * 1024) {
     kp.lut_lds = 1;
     return need + other;
@@ -293,20 +293,28 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
   sc.lds_pad = (int)lut_lds_bytes<T, M>(ka.kp, (size_t)sc_in.lds_pad);
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
-  if (general) {
-    EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, true, 1, -1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
-    return;
-  }
+  // look-up models: one instantiation per place the tables live in (LDS when they fit, lut_lds_bytes above)
+#define EXCENV_SIM_LAUNCH(GEN, VV, ST)                                                                                          \
+  do {                                                                                                                          \
+    if constexpr (M::HAS_LUT) {                                                                                                 \
+      if (ka.kp.lut_lds) {                                                                                                      \
+        EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, GEN, VV, ST, true>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); \
+        return;                                                                                                                 \
+      }                                                                                                                         \
+    }                                                                                                                           \
+    EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, GEN, VV, ST, false>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); \
+    return;                                                                                                                     \
+  } while (0)
+  if (general) EXCENV_SIM_LAUNCH(true, 1, -1);
   constexpr int VMAX = 16 / (int)sizeof(T);
-  if (ka.straj[0] == nullptr) {  // observations only: instantiated for the widest lanes (launch_sim routes the rest to `general`)
-    EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VMAX, 0>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
-    return;
-  }
+  if (ka.straj[0] == nullptr)  // observations only: instantiated for the widest lanes (launch_sim routes the rest to `general`)
+    EXCENV_SIM_LAUNCH(false, VMAX, 0);
   if constexpr (sizeof(T) == 4) {
-    if (V == 4) { EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 4, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); return; }
+    if (V == 4) EXCENV_SIM_LAUNCH(false, 4, 1);
   }
-  if (V == 2) { EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 2, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); return; }
-  EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, 1, 1>), grid, block, (size_t)sc.lds_pad, sc.stream, ka);
+  if (V == 2) EXCENV_SIM_LAUNCH(false, 2, 1);
+  EXCENV_SIM_LAUNCH(false, 1, 1);
+#undef EXCENV_SIM_LAUNCH
 }
 
 template <class M, typename T> static int launch_sim(const SimCall& sc) {
@@ -424,6 +432,13 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     // acrobot RK4 / Tsit5 is VALU-bound with the largest register footprint of all instantiations: two envs per lane keep
     // a third wave per SIMD resident (measured +7 % over four)
     if (sc.vec_pref == 0 && M::ID == EXCENV_ACROBOT && sc.solver != EXCENV_EULER && want > 2) want = 2;
+    // look-up models: the interpolation code per environment is large (instruction cache) and keeps six table values per
+    // environment live across the step (V = 4 needs > 256 registers): measured best at two environments per lane for Euler
+    // and one for RK4 / Tsit5
+    if (sc.vec_pref == 0 && M::HAS_LUT) {
+      const int cap = (sc.solver == EXCENV_EULER) ? 2 : 1;
+      if (want > cap) want = cap;
+    }
     if (want > VMAX) want = VMAX;
     while (want > 1 && (sc.B % want) != 0) want >>= 1;
     V = want;

@@ -19,7 +19,8 @@ template <typename T, class M> struct Ctx {
   const T* lut_gq;
   const T* lut_tab;
   int lut_nd, lut_nq;
-  int lut_lds;  // tables + grids staged in dynamic LDS (layout: tables, grid_d, grid_q)
+  int lut_lds;  // tables + grids staged in dynamic LDS (layout: tables, grid_d, grid_q, recip_d, recip_q)
+  T lut_g0[2], lut_sc[2];  // per grid (d, q): first node and (n - 1) / (last - first) — the arithmetic cell guess of find()
   // loop-invariant denominators (devmath.hpp InvDiv): (smax - smin) of every state field (normalisation) and the model's own
   InvDiv<T> nrm[M::S];
   InvDiv<T> den[M::ND > 0 ? M::ND : 1];
@@ -321,47 +322,58 @@ template <typename T> struct PmsmSat {
   // jax.scipy.interpolate.RegularGridInterpolator._find_indices: i = clip(searchsorted(g, x) - 1, 0, n - 2),
   // t = (x - g[i]) / (g[i+1] - g[i])  (not clipped: linear extrapolation; the padded edge makes it constant).
   // GP is a pointer to the grid in global memory or (address_space(3)) in LDS.
-  template <class GP> __device__ static __forceinline__ void find(GP g, int n, T x, int& i, T& t) {
-    // The reference's grids are np.linspace: guess the cell arithmetically, then make it exact against the stored
-    // grid values (same result as searchsorted(g, x, side="left") - 1 clipped to [0, n-2]); a non-uniform grid that
-    // defeats the guess falls back to a binary search.
-    const T g0 = g[0], gl = g[n - 1];
-    T gf = (x - g0) * (T(n - 1) / (gl - g0));
+  // g0 / sc: the grid's first node and (n - 1) / (last - first), trajectory invariants kept in the Ctx. rc: refined
+  // reciprocals of the cell widths (devmath.hpp InvDiv; staged next to the grids in LDS) or a null pointer -> plain division;
+  // either way t has the bits of (x - lo) / (hi - lo).
+  template <class GP>
+  __device__ static __forceinline__ void find(GP g, int n, T x, T g0, T sc, int& i, T& lo, T& hi) {
+    // The reference's grids are np.linspace: guess the cell arithmetically, then walk to the cell the stored grid values
+    // define (same result as searchsorted(g, x, side="left") - 1 clipped to [0, n-2]). On a uniform grid the guess is off by
+    // at most one, so each walk runs 0 or 1 times; on any other monotonic grid the walks still end in the right cell.
+    T gf = (x - g0) * sc;
     gf = (gf > T(0)) ? gf : T(0);  // also maps NaN to 0
     gf = (gf < T(n - 2)) ? gf : T(n - 2);
     int i0 = (int)gf;
-    T lo = g[i0], hi = g[i0 + 1];
-    if (!(lo < x) && i0 > 0) {
+    lo = g[i0];
+    hi = g[i0 + 1];
+    while (!(lo < x) && i0 > 0 && x == x) {  // x <= g[i0]: the cell is further down
       --i0;
       hi = lo;
       lo = g[i0];
-    } else if (hi < x && i0 < n - 2) {
+    }
+    while (hi < x && i0 < n - 2) {  // x > g[i0 + 1]: further up
       ++i0;
       lo = hi;
       hi = g[i0 + 1];
     }
-    const bool ok = (i0 == 0 || lo < x) && (i0 == n - 2 || !(hi < x));
-    if (__builtin_expect(!ok && x == x, 0)) {
-      int l = 0, h = n;
-      while (l < h) {  // first index with g[idx] >= x
-        const int mid = (l + h) >> 1;
-        if (g[mid] < x) l = mid + 1; else h = mid;
-      }
-      i0 = l - 1;
-      i0 = (i0 < 0) ? 0 : i0;
-      i0 = (i0 > n - 2) ? n - 2 : i0;
-      lo = g[i0];
-      hi = g[i0 + 1];
-    }
     i = i0;
-    t = (x - lo) / (hi - lo);
   }
   // six bilinear look-ups sharing one cell: _evaluate_linear's corner order (i,j), (i,j+1), (i+1,j), (i+1,j+1)
-  template <class GP> __device__ static __forceinline__ void lookup_at(GP gd, GP gq, GP tab, int nd, int nq, T i_d, T i_q, T (&q)[6]) {
+  // rd / rq: refined reciprocals of the cell widths (devmath.hpp InvDiv; staged next to the grids in LDS) when `fast`;
+  // either way the weights have the bits of (x - lo) / (hi - lo).
+  template <class GP>
+  __device__ static __forceinline__ void lookup_at(GP gd, GP gq, GP tab, GP rd, GP rq, bool fast, const C& c, T i_d, T i_q, T (&q)[6]) {
+    const int nd = c.lut_nd, nq = c.lut_nq;
     int ix, iy;
-    T tx, ty;
-    find(gd, nd, i_d, ix, tx);
-    find(gq, nq, i_q, iy, ty);
+    T lox, hix, loy, hiy, tx, ty;
+    find(gd, nd, i_d, c.lut_g0[0], c.lut_sc[0], ix, lox, hix);
+    find(gq, nq, i_q, c.lut_g0[1], c.lut_sc[1], iy, loy, hiy);
+    if (fast) {
+      InvDiv<T> wx, wy;
+      wx.b = hix - lox;
+      wx.y = rd[ix];
+      wy.b = hiy - loy;
+      wy.y = rq[iy];
+      const InvDiv<T>* w[2] = {&wx, &wy};
+      const T num[2] = {i_d - lox, i_q - loy};
+      T t[2];
+      div_all<2, T>(w, num, t, true);
+      tx = t[0];
+      ty = t[1];
+    } else {
+      tx = (i_d - lox) / (hix - lox);
+      ty = (i_q - loy) / (hiy - loy);
+    }
     const T w00 = (T(1) - tx) * (T(1) - ty), w01 = (T(1) - tx) * ty, w10 = tx * (T(1) - ty), w11 = tx * ty;
     GP n00 = tab + (ix * nq + iy) * 8;
     GP n10 = n00 + nq * 8;
@@ -374,19 +386,27 @@ template <typename T> struct PmsmSat {
       extern __shared__ __align__(16) unsigned char excenv_smem[];
       LP sm = (LP)excenv_smem;
       const int ntab = c.lut_nd * c.lut_nq * 8;
-      lookup_at<LP>(sm + ntab, sm + ntab + c.lut_nd, sm, c.lut_nd, c.lut_nq, i_d, i_q, q);
+      LP gd = sm + ntab, gq = gd + c.lut_nd, rd = gq + c.lut_nq, rq = rd + c.lut_nd;
+      lookup_at<LP>(gd, gq, sm, rd, rq, c.fastdiv, c, i_d, i_q, q);
     } else {
-      lookup_at<const T*>(c.lut_gd, c.lut_gq, c.lut_tab, c.lut_nd, c.lut_nq, i_d, i_q, q);
+      lookup_at<const T*>(c.lut_gd, c.lut_gq, c.lut_tab, nullptr, nullptr, false, c, i_d, i_q, q);
     }
   }
-  __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&st)[S], T (&dy)[NY]) {
+  // the vector field with the six interpolated values of its point already at hand (the trajectory kernels look a point up
+  // once and use it for the torque of the saved row and for the first stage of the step that starts there)
+  __device__ static __forceinline__ void f_q(const T (&y)[NY], const T (&u)[A], const C& c, const T (&st)[S], T (&dy)[NY],
+                                             const T (&q)[6]) {
     const T r_s = c.P[1], omega_el = st[6];
-    T q[6];
-    lookup(y[0], y[1], c, q);
     const T L_dd = q[0], L_dq = q[1], L_qd = q[2], L_qq = q[3], Psi_d = q[4], Psi_q = q[5];
     // 2x2 inverse in closed form (the reference calls jnp.linalg.inv: LU; parity of this model is unpinned anyway)
     const T det = L_dd * L_qq - L_dq * L_qd;
-    const T a00 = L_qq / det, a01 = -L_dq / det, a10 = -L_qd / det, a11 = L_dd / det;
+    InvDiv<T> by_det;  // four divisions by the same determinant: one reciprocal refinement (same bits as `/`, devmath.hpp)
+    by_det.init(det, c.fastdiv);
+    const InvDiv<T>* dd[4] = {&by_det, &by_det, &by_det, &by_det};
+    const T num[4] = {L_qq, -L_dq, -L_qd, L_dd};
+    T a[4];
+    div_all<4, T>(dd, num, a, c.fastdiv);
+    const T a00 = a[0], a01 = a[1], a10 = a[2], a11 = a[3];
     const T j0 = -Psi_q, j1 = Psi_d;  // J_k @ psi_dq, J_k = [[0,-1],[1,0]]
     const T d1_0 = (-a00 * r_s) * y[0] + (-a01 * r_s) * y[1];
     const T d1_1 = (-a10 * r_s) * y[0] + (-a11 * r_s) * y[1];
@@ -398,14 +418,28 @@ template <typename T> struct PmsmSat {
     dy[1] = d1_1 + d2_1 + d3_1;
     dy[2] = omega_el;
   }
+  __device__ static __forceinline__ void f(const T (&y)[NY], const T (&u)[A], const C& c, const T (&st)[S], T (&dy)[NY]) {
+    T q[6];
+    lookup(y[0], y[1], c, q);
+    f_q(y, u, c, st, dy, q);
+  }
+  __device__ static __forceinline__ T torque_q(T i_d, T i_q, const C& c, const T (&q)[6]) {
+    return T(1.5) * c.P[0] * (q[4] * i_q - q[5] * i_d);
+  }
   __device__ static __forceinline__ T torque(T i_d, T i_q, const C& c) {
     T q[6];
     lookup(i_d, i_q, c, q);
-    return T(1.5) * c.P[0] * (q[4] * i_q - q[5] * i_d);
+    return torque_q(i_d, i_q, c, q);
   }
   __device__ static __forceinline__ void post(T (&st)[S], const C& c) {
     st[2] = wrap_angle(st[2]);
     st[5] = torque(st[3], st[4], c);
+  }
+  // post() that also hands the look-up of the new operating point to the caller
+  __device__ static __forceinline__ void post_q(T (&st)[S], const C& c, T (&q)[6]) {
+    st[2] = wrap_angle(st[2]);
+    lookup(st[3], st[4], c, q);
+    st[5] = torque_q(st[3], st[4], c, q);
   }
   __device__ static __forceinline__ void observe(const T (&st)[S], const C& c, T (&ob)[O]) { L::observe(st, c, ob); }
   __device__ static __forceinline__ void constraint(const T (&a)[A], T eps, T omega_el, const C& c, T (&uc)[2]) {

@@ -47,13 +47,23 @@ template <> struct Tableau<EXCENV_TSIT5> {
 // callable evaluated AT that stage: on the sim_ahead path it reads the prefetched next action row, and the s_waitcnt for that
 // load sits in front of the first instruction that touches those registers — evaluated up front, every solver step would
 // start by waiting for a load issued a few hundred instructions earlier.
+// q0 (look-up models only): the interpolated table values at the step's starting point when the caller already has them.
 template <class M, int SOLVER, typename T, class U1>
 __device__ __forceinline__ void rk_step(T (&y)[M::NY], const T (&u)[M::A], U1&& u1_of, const Ctx<T, M>& c,
-                                        const T (&st)[M::S]) {
+                                        const T (&st)[M::S], const T (*q0)[6] = nullptr) {
   constexpr int NY = M::NY;
   T dy[NY];
+  auto f_first = [&](const T (&yy)[NY], T (&d)[NY]) __attribute__((always_inline)) {
+    if constexpr (M::HAS_LUT) {
+      if (q0 != nullptr) {
+        M::f_q(yy, u, c, st, d, *q0);
+        return;
+      }
+    }
+    M::f(yy, u, c, st, d);
+  };
   if constexpr (SOLVER == EXCENV_EULER) {
-    M::f(y, u, c, st, dy);
+    f_first(y, dy);
 #pragma unroll
     for (int j = 0; j < NY; ++j) y[j] = y[j] + dy[j] * c.dt;
   } else {
@@ -76,6 +86,8 @@ __device__ __forceinline__ void rk_step(T (&y)[M::NY], const T (&u)[M::A], U1&& 
         T u1[M::A];
         u1_of(u1);
         M::f(yi, u1, c, st, dy);
+      } else if (s == 0) {
+        f_first(yi, dy);
       } else {
         M::f(yi, u, c, st, dy);
       }
@@ -96,8 +108,9 @@ __device__ __forceinline__ void rk_step(T (&y)[M::NY], const T (&u)[M::A], U1&& 
 }
 
 // One reference `step` on the carried state (CoreEnvironment.step core_env.py:393-425; PMSM.step pmsm_env.py:851-883).
+// memo (look-up models, trajectory kernels): in = the table values at the state's operating point, out = those at the new one.
 template <class M, int SOLVER, typename T>
-__device__ __forceinline__ void env_step(T (&st)[M::S], const T (&a)[M::A], const Ctx<T, M>& c) {
+__device__ __forceinline__ void env_step(T (&st)[M::S], const T (&a)[M::A], const Ctx<T, M>& c, T (*memo)[6] = nullptr) {
   T u[M::A];
   if constexpr (M::IS_PMSM) {
     T uc[2];
@@ -116,8 +129,14 @@ __device__ __forceinline__ void env_step(T (&st)[M::S], const T (&a)[M::A], cons
   rk_step<M, SOLVER>(y, u, [&](T (&u1)[M::A]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < M::A; ++q) u1[q] = u[q];
-  }, c, st);
+  }, c, st, memo);
   M::set_y(st, y);
+  if constexpr (M::HAS_LUT) {
+    if (memo != nullptr) {
+      M::post_q(st, c, *memo);
+      return;
+    }
+  }
   M::post(st, c);
 }
 
@@ -131,7 +150,8 @@ template <typename T> struct AheadAux {
 // (pmsm_env.py:719-722) and applies actions_dead[k] (:766-777).
 template <class M, int SOLVER, typename T>
 __device__ __forceinline__ void env_advance_raw(T (&st)[M::S], const T (&a)[M::A], const T (&a1)[M::A], int64_t k,
-                                                int64_t k1, const Ctx<T, M>& c, AheadAux<T>& aux) {
+                                                int64_t k1, const Ctx<T, M>& c, AheadAux<T>& aux,
+                                                const T (*q0)[6] = nullptr) {
   T u[M::A];
   T uc[2] = {T(0), T(0)};
   bool dead = false;
@@ -160,7 +180,7 @@ __device__ __forceinline__ void env_advance_raw(T (&st)[M::S], const T (&a)[M::A
   };
   T y[M::NY];
   M::get_y(st, y);
-  rk_step<M, SOLVER>(y, u, u1_of, c, st);
+  rk_step<M, SOLVER>(y, u, u1_of, c, st, q0);
   M::set_y(st, y);
 }
 
