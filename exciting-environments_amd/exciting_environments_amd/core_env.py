@@ -520,9 +520,14 @@ class CoreEnvironment(ABC):
         sl.use0 = [CoreEnvironment._storage_use_count(st._cdata) for st in sl.storages]
 
     def _slots_per_alloc(self, gym: bool) -> int:
+        """Slots per pool: ~4 MiB worth, at most 32; never fewer than 3 (the input state, the output and one dead slot —
+        below that nothing can ever be recycled) unless three slots would exceed 1 GiB."""
         isz = 4 if self.dtype == torch.float32 else 8
         per = self.batch_size * (self.physical_state_dim + self._obs_dim() + (1 if gym else 0)) * isz
-        return max(1, min(32, (4 << 20) // max(per, 1)))
+        n = max(1, min(32, (4 << 20) // max(per, 1)))
+        if n < 3 and 3 * per <= (1 << 30):
+            n = 3
+        return n
 
     def _vmap_step_launch(self, state, action, gym: bool, obs_refs=None):
         B = self.batch_size

@@ -14,3 +14,9 @@ for w in msd_euler_f32 tank_euler_f32 cartpole_euler_f32 acrobot_euler_f32 pmsm_
   python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/profile_round2/$w.json 2>> gpurun_out/profile_round2/err.txt
 done
 python bench.py --obs-only --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/profile_round2/pmsm_obsonly.json 2>> gpurun_out/profile_round2/err.txt
+bash tools/profile_gpu.sh r02_em_pmsm_euler_f32 --traj-layout env_major --action-layout env_major > gpurun_out/profile_round2/prof_em.log 2>&1
+for w in pmsm_tsit5_f32 acrobot_tsit5_f32 pendulum_euler_f32 msd_tsit5_f64 pmsm_sat_euler_f64; do
+  python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/profile_round2/$w.json 2>> gpurun_out/profile_round2/err.txt
+done
+python tools/host_overhead.py > gpurun_out/profile_round2/host_overhead.txt 2>&1
+python tools/batch_sweep.py > gpurun_out/profile_round2/batch_sweep.txt 2>&1
