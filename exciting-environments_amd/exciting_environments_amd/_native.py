@@ -97,6 +97,8 @@ def lib():
         # typed prototypes: plain Python ints / floats / None / byref() pass without per-call ctypes wrapping
         l.excenv_step.argtypes = [ci, ci, ci, cl, vp, vp, cd, vp, vp, vp, vp, vp, vp]
         l.excenv_gym_step.argtypes = [ci, ci, ci, cl, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.excenv_sim_ahead_ws.argtypes = [ci, ci, ci, cl, cl, ctypes.c_int32, vp, vp, cd, cd, vp, vp, ci, vp, vp, ci, vp, ci, vp,
+                                          vp, cl, vp, vp]
         if l.excenv_abi_version() != ABI_VERSION:
             raise ImportError("libexcenv_hip.so: ABI version mismatch")
         _lib = l
@@ -277,6 +279,18 @@ def sim_ahead(env_id, solver_id, dtype, B, K, substeps, props: Props, control: O
             _opts_ref(opts), ctypes.c_void_p(stream),
         )
     _check(rc, "excenv_sim_ahead")
+
+
+def sim_ahead_raw(env_id, solver_id, dtype_code, B, K, substeps, props_ref, control_ref, obs_stepsize, env_tau, in_ptrs,
+                  actions_ptr, action_layout, obs_ptr, traj_ptrs, traj_layout, last_ptrs, semantics, ws_ptr, ws_bytes, opts_ref,
+                  stream):
+    """excenv_sim_ahead_ws with every argument already in its C form (the fast path of vmap_sim_ahead: lane-major
+    trajectories, no gym outputs). The caller has made the buffers' device current."""
+    rc = _lib.excenv_sim_ahead_ws(env_id, solver_id, dtype_code, B, K, substeps, props_ref, control_ref, obs_stepsize, env_tau,
+                                  in_ptrs, actions_ptr, action_layout, obs_ptr, traj_ptrs, traj_layout, last_ptrs, semantics,
+                                  None, ws_ptr, ws_bytes, opts_ref, stream)
+    if rc != 0:
+        _check(rc, "excenv_sim_ahead")
 
 
 def rew_trunc_term(env_id, dtype, B, rows, props: Props, control: Optional[Control], ref_strides: Optional[Sequence[int]],

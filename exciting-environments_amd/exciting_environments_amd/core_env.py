@@ -115,6 +115,8 @@ class CoreEnvironment(ABC):
         # vmap_step fast path (see _vmap_step_launch): output slots carved from one allocation per `n` calls, pointer arrays
         # pre-built per slot, and the identity of the state we returned last (its pointer array is the next call's input)
         self._slots = {False: None, True: None}
+        self._traj_bcast_cache = None
+        self._ws_bytes_cache = None
         self._last_out = None
         self._ctl_cache = None
         self._active_additions = None
@@ -783,6 +785,9 @@ class CoreEnvironment(ABC):
             a_layout = _native.LAYOUT_ENV_MAJOR
 
         want_states = self.store_state_trajectory
+        if self.traj_layout == "lane_major" and not want_gym and B > 0 and self.device.type == "cuda":
+            return self._run_sim_ahead_lane_major(init_state, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub,
+                                                  want_states)
         if self.traj_layout == "lane_major":
             obs_buf = torch.empty((N + 1, OW, B), dtype=self.dtype, device=self.device)
             st_buf = [torch.empty((N + 1, B), dtype=self.dtype, device=self.device) for _ in range(S)] if want_states else None
@@ -840,19 +845,96 @@ class CoreEnvironment(ABC):
             return observations, st_views, last, N, gym_out
         return observations, st_views, last, N
 
+    # Trajectories up to this size come out of ONE allocation (observations, state leaves and last_state are views of it):
+    # at RL / MPC batch sizes the launch takes ~100 us and 2 S + 1 allocator calls plus as many view objects cost as much.
+    # Larger outputs keep one allocation per returned array so that dropping the states frees their memory.
+    _SHARED_TRAJ_BYTES = 32 << 20
+
+    def _run_sim_ahead_lane_major(self, init_state, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub,
+                                  want_states):
+        """The default layout without gym outputs: buffers carved from one or two allocations, pointers computed from the base
+        address, one ctypes call with plain arguments (same launch as the general path below)."""
+        S, OW = self.physical_state_dim, self._obs_dim()
+        N = K * sub
+        rows = N + 1
+        dt, dev = self.dtype, self.device
+        isz = 4 if dt is torch.float32 else 8
+        al = 16 // isz
+        up = lambda n: (n + al - 1) // al * al
+        obs_e, leaf_e, last_e = up(rows * OW * B), up(rows * B), up(B)
+        traj_e = obs_e + (S * leaf_e if want_states else 0)
+        opts = self.launch_opts
+        ws_e = ws_bytes = 0
+        if a_layout == _native.LAYOUT_ENV_MAJOR:  # row-major actions: transposed through scratch by the library
+            if not self.env_major_fused:
+                opts = _native.launch_opts(opts.envs_per_lane if opts else 0, 1, opts.lds_pad_bytes if opts else 0)
+            if self.env_major_workspace:
+                wk = (B, K, sub, len(self.control_state), want_states)
+                if self._ws_bytes_cache is None or self._ws_bytes_cache[0] != wk:
+                    self._ws_bytes_cache = (wk, _native.sim_ahead_workspace_bytes(
+                        self.ENV_ID, dt, B, K, sub, len(self.control_state), a_layout, _native.LAYOUT_LANE_MAJOR, want_states))
+                ws_bytes = self._ws_bytes_cache[1]
+                ws_e = up((ws_bytes + isz - 1) // isz)
+        shared = (traj_e + S * last_e + ws_e) * isz <= self._SHARED_TRAJ_BYTES
+        st_views = None
+        ws_ptr = None
+        if shared:
+            buf = torch.empty(traj_e + S * last_e + ws_e, dtype=dt, device=dev)
+            base = buf.data_ptr()
+            if ws_e:
+                ws_ptr = base + (traj_e + S * last_e) * isz
+            observations = buf.as_strided((B, rows, OW), (1, OW * B, B))
+            if want_states:
+                st_views = buf.as_strided((S, B, rows), (leaf_e, 1, B), obs_e).unbind(0)
+                traj_ptrs = _native.ptr_array([base + (obs_e + j * leaf_e) * isz for j in range(S)])
+            last = buf.as_strided((S, B), (last_e, 1), traj_e).unbind(0)
+            last_ptrs = _native.ptr_array([base + (traj_e + j * last_e) * isz for j in range(S)])
+            obs_ptr = base
+        else:
+            obs_buf = torch.empty((rows, OW, B), dtype=dt, device=dev)
+            observations = obs_buf.permute(2, 0, 1)
+            obs_ptr = obs_buf.data_ptr()
+            if want_states:
+                st_buf = [torch.empty((rows, B), dtype=dt, device=dev) for _ in range(S)]
+                st_views = [b.t() for b in st_buf]
+                traj_ptrs = _native._ptrs(st_buf)
+            lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
+            last = lbuf[:, :B].unbind(0)
+            lb = lbuf.data_ptr()
+            last_ptrs = _native.ptr_array([lb + j * last_e * isz for j in range(S)])
+            if ws_e:
+                ws = torch.empty(ws_e, dtype=dt, device=dev)  # stream-ordered: free to die when this function returns
+                ws_ptr = ws.data_ptr()
+        sem = _native.SEM_AHEAD if self.sim_ahead_semantics == "ahead" else _native.SEM_STEP
+        with _native._on_device(dev):
+            _native.sim_ahead_raw(self.ENV_ID, self._solver.id, 0 if dt is torch.float32 else 1, B, K, sub, ctypes.byref(props),
+                                  ctypes.byref(control) if control is not None else None, float(obs_stepsize), float(self.tau),
+                                  _native._ptrs(st_in), actions.data_ptr() if K > 0 else None, a_layout, obs_ptr,
+                                  traj_ptrs if want_states else None, _native.LAYOUT_LANE_MAJOR, last_ptrs, sem, ws_ptr,
+                                  ws_bytes if ws_ptr is not None else 0, None if opts is None else ctypes.byref(opts),
+                                  _native._raw_stream(dev))
+        return observations, st_views, last, N
+
     def _traj_state(self, init_state, st_views, lead_shape, N):
         """Rebuild the State pytree of a trajectory: reference / PRNGKey broadcast along the saved rows,
         active_solver_state all True (e.g. pendulum_env.py:243-259)."""
         shape = lead_shape + (N + 1,)
-        phys = self.PhysicalState(**dict(zip(self.STATE_FIELDS, st_views)))
-        ref = self.PhysicalState(**{
-            n: self._t(getattr(init_state.reference, n)).reshape(lead_shape + (1,)).expand(shape)
-            for n in self.STATE_FIELDS
-        })
-        if _random.is_key(init_state.PRNGKey):
-            key = init_state.PRNGKey.reshape(lead_shape + (1, 2)).expand(shape + (2,))
+        phys = self.PhysicalState(*st_views)
+        # the broadcast reference / key leaves depend only on the incoming leaves and the row count: keep the views of the last
+        # call (the cache holds the source leaves, so their ids cannot be reused while it is valid)
+        src = tuple(getattr(init_state.reference, n) for n in self.STATE_FIELDS) + (init_state.PRNGKey,)
+        ck = self._traj_bcast_cache
+        if ck is not None and ck[0] == shape and len(ck[1]) == len(src) and all(a is b for a, b in zip(ck[1], src)):
+            ref, key = ck[2], ck[3]
         else:
-            key = self._t(init_state.PRNGKey).reshape(lead_shape + (1,)).expand(shape)
+            ref = self.PhysicalState(*[
+                self._t(r).reshape(lead_shape + (1,)).expand(shape) for r in src[:-1]
+            ])
+            if _random.is_key(init_state.PRNGKey):
+                key = init_state.PRNGKey.reshape(lead_shape + (1, 2)).expand(shape + (2,))
+            else:
+                key = self._t(init_state.PRNGKey).reshape(lead_shape + (1,)).expand(shape)
+            self._traj_bcast_cache = (shape, src, ref, key)
         return self.State(physical_state=phys, PRNGKey=key, additions=self._additions(shape, True), reference=ref)
 
     def sim_ahead(self, init_state, actions, env_properties, obs_stepsize, action_stepsize):
@@ -915,8 +997,7 @@ class CoreEnvironment(ABC):
                                 PRNGKey=None, additions=None, reference=None)
         else:
             states = self._traj_state(init_state, st_views, (B,), N)
-        last_state = replace(init_state, physical_state=self.PhysicalState(**dict(zip(self.STATE_FIELDS, last))),
-                             additions=self._additions((B,), True))
+        last_state = self.State(self.PhysicalState(*last), init_state.PRNGKey, self._additions((B,), True), init_state.reference)
         if gym_out is not None:
             return (obs, states, last_state) + tuple(gym_out)
         return obs, states, last_state

@@ -52,6 +52,22 @@ for name in ("PENDULUM", "PMSM"):
             stp.run()
         torch.cuda.synchronize()
         print(f"{name}: {(time.perf_counter() - t0) / (300 * 16) * 1e6:.2f} us per step, Stepper(n_steps=16, graph={graph})")
+    for K in (10, 100):  # vmap_sim_ahead: host + launch per call (the kernel itself takes ~1 us per solver step at this size)
+        acts = torch.zeros((1024, K, env.action_dim), device="cuda:0")
+        lm = env.new_actions_buffer(K)
+        for a, tag in ((acts, "row-major actions"), (lm, "lane-major actions")):
+            for _ in range(20):
+                env.vmap_sim_ahead(state, a, env.tau, env.tau)
+            torch.cuda.synchronize()
+            best = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(500):
+                    out = env.vmap_sim_ahead(state, a, env.tau, env.tau)
+                t_host = (time.perf_counter() - t0) / 500
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / 500)
+            print(f"{name}: vmap_sim_ahead K={K} ({tag}): {best * 1e6:.1f} us per call end to end, {t_host * 1e6:.1f} us host time to enqueue")
     from exciting_environments_amd import GymWrapper
     gw = GymWrapper(env)
     for _ in range(50):
