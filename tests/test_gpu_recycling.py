@@ -119,3 +119,41 @@ def test_gym_wrapper_loop_recycles_and_keeps_its_results():
         # no reference generator: the reference column (and with it the reward) is NaN -> compare bit patterns
         assert torch.equal(obs.view(torch.int32), obs_c.view(torch.int32)), k
         assert torch.equal(rew.view(torch.int32), rew_c.view(torch.int32)), k
+
+
+@pytest.mark.parametrize("actions_layout", ["row_major", "lane_major"])
+def test_sim_ahead_single_allocation_outputs_equal_separately_allocated_ones(actions_layout):
+    """vmap_sim_ahead carves observations, state trajectories and last_state of small problems out of one allocation
+    (core_env.py _run_sim_ahead_lane_major); same values as with one allocation per array, shapes / strides as before, and a
+    later call never touches what an earlier one returned."""
+    env, state, _ = _env("PMSM")
+    K = 12
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    acts = torch.rand((B, K, env.action_dim), generator=g, device="cuda") * 2 - 1
+    if actions_layout == "lane_major":
+        buf = env.new_actions_buffer(K)
+        buf.copy_(acts)
+        acts = buf
+    obs1, st1, last1 = env.vmap_sim_ahead(state, acts, env.tau, env.tau)
+    assert obs1.untyped_storage().data_ptr() == st1.physical_state.i_d.untyped_storage().data_ptr()  # shared path taken
+    keep = (obs1.clone(), st1.physical_state.i_q.clone(), last1.physical_state.epsilon.clone())
+    type(env)._SHARED_TRAJ_BYTES, saved = 0, type(env)._SHARED_TRAJ_BYTES
+    try:
+        obs2, st2, last2 = env.vmap_sim_ahead(state, acts, env.tau, env.tau)
+    finally:
+        type(env)._SHARED_TRAJ_BYTES = saved
+    assert obs2.untyped_storage().data_ptr() != st2.physical_state.i_d.untyped_storage().data_ptr()
+    assert obs1.shape == obs2.shape == (B, K + 1, 8) and obs1.stride() == obs2.stride()
+    assert torch.equal(obs1, obs2)
+    for f in env.STATE_FIELDS:
+        a, b = getattr(st1.physical_state, f), getattr(st2.physical_state, f)
+        assert a.shape == b.shape == (B, K + 1) and a.stride() == b.stride() and torch.equal(a, b), f
+        assert torch.equal(getattr(last1.physical_state, f), getattr(last2.physical_state, f)), f
+        assert torch.equal(getattr(last1.physical_state, f), a[:, -1] if f not in ("u_d_buffer", "u_q_buffer") else
+                           getattr(last1.physical_state, f))
+    for _ in range(3):
+        env.vmap_sim_ahead(last1, acts, env.tau, env.tau)
+    torch.cuda.synchronize()
+    assert torch.equal(obs1, keep[0]) and torch.equal(st1.physical_state.i_q, keep[1])
+    assert torch.equal(last1.physical_state.epsilon, keep[2])
