@@ -564,6 +564,40 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   publish_last(sv);
 }
 
+// ---- reference-tracking observation columns of a trajectory (control_state; e.g. pendulum_env.py:311-329) --------------
+// They are constant along the trajectory: the normalised reference of each controlled field, repeated on every row. With
+// broadcast properties and no gym outputs the trajectory itself is produced by the lean (vectorised) sim_ahead_kernel, which
+// leaves these columns of the observation buffer untouched, and this kernel fills them: one 16-byte store per (4 environments,
+// row, column) in the lane-major / tiled layouts. Same values as the GENERAL kernel writes (plain normalize()).
+template <typename T, class M> struct ControlFillArgs {
+  KProps<T, M> kp;
+  int64_t B, rows;
+  int32_t n_control, tiled;
+  int32_t control_idx[EXCENV_MAX_CONTROL];
+  const T* reference[EXCENV_MAX_CONTROL];
+  T* obs;
+  int64_t o_sk, o_sc, tile_pitch;  // element strides: row, column; tiled: elements per tile
+};
+
+template <class M, typename T, int V> __global__ void __launch_bounds__(BLOCK) control_fill_kernel(const ControlFillArgs<T, M> ka) {
+  const int64_t b0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * V;
+  if (b0 >= ka.B) return;
+  T* base = ka.obs + (ka.tiled ? (b0 / EXCENV_TILE) * ka.tile_pitch + (b0 % EXCENV_TILE) : b0);
+#pragma unroll
+  for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+    if (j < ka.n_control) {
+      const int f = ka.control_idx[j];
+      const T lo = ka.kp.scalar[M::P + f], hi = ka.kp.scalar[M::P + M::S + f];
+      T r[V], c[V];
+      load_v<T, V>(ka.reference[j] + b0, r);
+#pragma unroll
+      for (int v = 0; v < V; ++v) c[v] = normalize(r[v], lo, hi);
+      T* col = base + (M::O + j) * ka.o_sc;
+      for (int64_t n = blockIdx.y; n < ka.rows; n += gridDim.y) store_stream<T, V>(col + n * ka.o_sk, c);
+    }
+  }
+}
+
 // ---- generate_rew_trunc_term_ahead on a stored trajectory (core_env.py:490-531, 618-647) -----------------------------
 // One thread per (env, row) of the state trajectories a previous vmap_sim_ahead returned (any of its layouts: the host
 // passes element strides and says which of the two indices is the contiguous one). reward / terminated are written for

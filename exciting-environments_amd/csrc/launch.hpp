@@ -334,7 +334,15 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   const int64_t N = sc.K * sc.substeps;
   const int64_t OW = M::O + ka.n_control;
   const bool with_gym = sc.gym != nullptr;
-  bool general = batched || ka.n_control > 0 || with_gym;
+  // control_state columns alone (broadcast properties, no gym outputs, lane-major / tiled trajectories) do not need the
+  // one-environment-per-lane GENERAL kernel: they are constant along the trajectory and are filled by control_fill_kernel
+  // after the lean kernel has written everything else (same bytes, +1 launch, 0.52 -> 0.7 of the HBM roof at B = 2^22)
+  bool split_control = !batched && !with_gym && ka.n_control > 0 && sc.traj_layout != EXCENV_LAYOUT_ENV_MAJOR &&
+                       sc.action_layout != EXCENV_LAYOUT_ENV_MAJOR && sc.B > 0;
+  if (split_control) {
+    for (int j = 0; j < ka.n_control; ++j) split_control &= sc.control->reference[j] != nullptr;
+  }
+  bool general = batched || (ka.n_control > 0 && !split_control) || with_gym;
   bool vec_ok = !general;
   for (int j = 0; j < M::S; ++j) {
     if (!sc.state_in[j] || !sc.last_state[j]) { set_error("excenv_sim_ahead: state pointer %d is NULL", j); return EXCENV_ENULL; }
@@ -482,7 +490,35 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
   }
 #undef EXCENV_SIM_CASE
-  return check_launch("excenv_sim_ahead");
+  if (int rc = check_launch("excenv_sim_ahead")) return rc;
+  if (split_control && !general) {
+    ControlFillArgs<T, M> fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.kp = ka.kp;
+    fa.B = sc.B;
+    fa.rows = N + 1;
+    fa.n_control = ka.n_control;
+    fa.tiled = tiled_t ? 1 : 0;
+    for (int j = 0; j < ka.n_control; ++j) {
+      fa.control_idx[j] = ka.control_idx[j];
+      fa.reference[j] = ka.reference[j];
+    }
+    fa.obs = ka.obs;
+    fa.o_sk = ka.o_sk;
+    fa.o_sc = ka.o_sc;
+    fa.tile_pitch = (N + 1) * OW * TILE;
+    bool v4 = (sizeof(T) == 4) && (sc.B % 4 == 0) && aligned16(ka.obs);
+    for (int j = 0; j < ka.n_control; ++j) v4 &= aligned16(fa.reference[j]);
+    const int64_t lanes = v4 ? sc.B / 4 : sc.B;
+    const dim3 fgrid((unsigned)((lanes + BLOCK - 1) / BLOCK), (unsigned)((N + 1 < 64) ? N + 1 : 64)), fblock(BLOCK);
+    if (v4) {
+      if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((control_fill_kernel<M, T, 4>), fgrid, fblock, 0, sc.stream, fa);
+    } else {
+      hipLaunchKernelGGL((control_fill_kernel<M, T, 1>), fgrid, fblock, 0, sc.stream, fa);
+    }
+    return check_launch("excenv_sim_ahead (control columns)");
+  }
+  return EXCENV_OK;
 }
 
 template <class M, typename T> static int launch_traj_gym(const TrajGymCall& gc) {
