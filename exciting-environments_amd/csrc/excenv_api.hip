@@ -309,6 +309,29 @@ int excenv_update_ref(int env, int dtype, int64_t B, const excenv_props_t* props
   return t->update_ref(rc);
 }
 
+int excenv_update_ref_to(int env, int dtype, int64_t B, const excenv_props_t* props, int32_t n_control,
+                         const int32_t* control_idx, const void* const* reference_in, const int64_t* keys_in,
+                         const int64_t* hold_in, void* const* reference_out, int64_t* keys_out, int64_t* hold_out,
+                         int32_t hold_steps_min, int32_t hold_steps_max, void* stream) {
+  if (int rc = check_common("excenv_update_ref_to", env, 0, dtype, B)) return rc;
+  if (n_control < 0 || n_control > EXCENV_MAX_CONTROL) { set_error("excenv_update_ref_to: bad n_control %d", n_control); return EXCENV_EINVAL; }
+  if (!props || !keys_in || !hold_in || !keys_out || !hold_out || (n_control > 0 && (!control_idx || !reference_in || !reference_out))) {
+    set_error("excenv_update_ref_to: NULL argument");
+    return EXCENV_ENULL;
+  }
+  if (keys_in == keys_out || hold_in == hold_out) { set_error("excenv_update_ref_to: outputs must not alias the inputs (use excenv_update_ref)"); return EXCENV_EINVAL; }
+  for (int j = 0; j < n_control; ++j) {
+    if (control_idx[j] < 0 || control_idx[j] >= table_public(env)->S) { set_error("excenv_update_ref_to: control_idx[%d] out of range", j); return EXCENV_EINVAL; }
+    if (reference_in[j] == reference_out[j]) { set_error("excenv_update_ref_to: outputs must not alias the inputs (use excenv_update_ref)"); return EXCENV_EINVAL; }
+  }
+  int trc;
+  const EnvVTable* t = table_for(env, props, &trc);
+  if (!t) return trc;
+  RefGenCall rc{dtype, B, props, n_control, control_idx, reference_out, keys_out, hold_out, hold_steps_min, hold_steps_max,
+                (hipStream_t)stream, reference_in, keys_in, hold_in};
+  return t->update_ref(rc);
+}
+
 int excenv_random_state(int env, int dtype, int64_t B, const excenv_props_t* props, const int64_t* keys,
                         void* const* state_out, int64_t* key_leaf, void* stream) {
   if (int rc = check_common("excenv_random_state", env, 0, dtype, B)) return rc;

@@ -99,6 +99,10 @@ struct RefGenCall {
   int64_t* hold;
   int32_t hold_min, hold_max;
   hipStream_t stream;
+  // inputs of the out-of-place form (nullptr: in place)
+  const void* const* reference_in = nullptr;
+  const int64_t* keys_in = nullptr;
+  const int64_t* hold_in = nullptr;
 };
 
 struct RandomStateCall {
@@ -592,9 +596,13 @@ template <class M, typename T> static int launch_update_ref(const RefGenCall& rc
     if (!rc.reference[j]) { set_error("excenv_update_ref: reference pointer %d is NULL", j); return EXCENV_ENULL; }
     ka.control_idx[j] = rc.control_idx[j];
     ka.reference[j] = (T*)rc.reference[j];
+    ka.reference_in[j] = rc.reference_in ? (const T*)rc.reference_in[j] : (const T*)rc.reference[j];
+    if (!ka.reference_in[j]) { set_error("excenv_update_ref: reference_in pointer %d is NULL", j); return EXCENV_ENULL; }
   }
   ka.keys = rc.keys;
   ka.hold = rc.hold;
+  ka.keys_in = rc.keys_in ? rc.keys_in : rc.keys;
+  ka.hold_in = rc.hold_in ? rc.hold_in : rc.hold;
   ka.hold_min = rc.hold_min;
   ka.hold_max = rc.hold_max;
   if (rc.B == 0) return EXCENV_OK;

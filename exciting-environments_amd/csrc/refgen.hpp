@@ -184,9 +184,13 @@ template <typename T, class M> struct RefGenArgs {
   int64_t B;
   int32_t n_control;
   int32_t control_idx[EXCENV_MAX_CONTROL];
-  T* reference[EXCENV_MAX_CONTROL];  // in/out: [B] reference leaf of controlled field j
-  int64_t* keys;                     // in/out: [B][2] uint32 key words held in int64 (the Python mirror's key tensors)
-  int64_t* hold;                     // in/out: [B] hold counters
+  T* reference[EXCENV_MAX_CONTROL];  // out: [B] reference leaf of controlled field j
+  int64_t* keys;                     // out: [B][2] uint32 key words held in int64 (the Python mirror's key tensors)
+  int64_t* hold;                     // out: [B] hold counters
+  // inputs (== the outputs for the in-place form)
+  const T* reference_in[EXCENV_MAX_CONTROL];
+  const int64_t* keys_in;
+  const int64_t* hold_in;
   int32_t hold_min, hold_max;
 };
 
@@ -194,11 +198,12 @@ template <class M, typename T> __global__ void __launch_bounds__(BLOCK) update_r
   constexpr int S = M::S;
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= ka.B) return;
-  int64_t h = ka.hold[i];
+  int64_t h = ka.hold_in[i];
+  const bool copy = ka.keys != ka.keys_in;  // out-of-place: environments that are not due carry their values over
   if (h == 0) {
     Ctx<T, M> c;
     load_ctx<true, T, M, false>(c, ka.kp, i, T(0), T(0), T(0));
-    Key key{(uint32_t)ka.keys[2 * i], (uint32_t)ka.keys[2 * i + 1]};
+    Key key{(uint32_t)ka.keys_in[2 * i], (uint32_t)ka.keys_in[2 * i + 1]};
     T phys[S];
     Key leaf;
     init_state_from_key<M, T>(key, c, phys, leaf);
@@ -216,6 +221,12 @@ template <class M, typename T> __global__ void __launch_bounds__(BLOCK) update_r
     h = rng_randint(sub, ka.hold_min, ka.hold_max);
     ka.keys[2 * i] = (int64_t)k_new.k0;
     ka.keys[2 * i + 1] = (int64_t)k_new.k1;
+  } else if (copy) {
+#pragma unroll
+    for (int j = 0; j < EXCENV_MAX_CONTROL; ++j)
+      if (j < ka.n_control) ka.reference[j][i] = ka.reference_in[j][i];
+    ka.keys[2 * i] = ka.keys_in[2 * i];
+    ka.keys[2 * i + 1] = ka.keys_in[2 * i + 1];
   }
   ka.hold[i] = h - 1;
 }

@@ -91,7 +91,7 @@ def lib():
         l.excenv_truncated_width.restype = ctypes.c_int32
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
                    "excenv_probe_math", "excenv_probe_div", "excenv_rew_trunc_term", "excenv_state_from_observation",
-                   "excenv_update_ref", "excenv_random_state"):
+                   "excenv_update_ref", "excenv_update_ref_to", "excenv_random_state"):
             getattr(l, fn).restype = ctypes.c_int
         vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
         # typed prototypes: plain Python ints / floats / None / byref() pass without per-call ctypes wrapping
@@ -335,6 +335,24 @@ def update_ref(env_id, dtype, B, props: Props, control_idx: Sequence[int], refer
             ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(hold.data_ptr()), ctypes.c_int32(hold_min), ctypes.c_int32(hold_max),
             ctypes.c_void_p(_raw_stream(keys.device)))
     _check(rc, "excenv_update_ref")
+
+
+def update_ref_to(env_id, dtype, B, props: Props, control_idx: Sequence[int], reference_in: Sequence[torch.Tensor],
+                  keys_in: torch.Tensor, hold_in: torch.Tensor, reference_out: Sequence[torch.Tensor], keys_out: torch.Tensor,
+                  hold_out: torch.Tensor, hold_min: int, hold_max: int):
+    """excenv_update_ref_to: out-of-place reference redraw + hold countdown (inputs untouched, one launch, no copies)."""
+    _require_device(keys_in, "GymWrapper.update_ref")
+    for t in (keys_in, hold_in, keys_out, hold_out):
+        assert t.dtype == torch.int64 and t.is_contiguous()
+    nc = len(control_idx)
+    with _on_device(keys_in.device):
+        rc = lib().excenv_update_ref_to(
+            ctypes.c_int(env_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B), ctypes.byref(props), ctypes.c_int32(nc),
+            (ctypes.c_int32 * nc)(*control_idx) if nc else None, _ptrs(reference_in) if nc else None,
+            ctypes.c_void_p(keys_in.data_ptr()), ctypes.c_void_p(hold_in.data_ptr()), _ptrs(reference_out) if nc else None,
+            ctypes.c_void_p(keys_out.data_ptr()), ctypes.c_void_p(hold_out.data_ptr()), ctypes.c_int32(hold_min),
+            ctypes.c_int32(hold_max), ctypes.c_void_p(_raw_stream(keys_in.device)))
+    _check(rc, "excenv_update_ref_to")
 
 
 def random_state(env_id, dtype, B, props: Props, keys: torch.Tensor, state_out: Sequence[torch.Tensor], key_leaf: torch.Tensor):

@@ -103,12 +103,22 @@ class GymWrapper:
         B = env.batch_size
         idx = [env.STATE_FIELDS.index(n) for n in self.control_state]
         old_refs = [env._t(getattr(state.reference, n), (B,)) for n in self.control_state]
-        new_refs = [r.clone() for r in old_refs]
-        keys = state.PRNGKey.to(device=env.device, dtype=torch.int64).clone().contiguous()
-        hold = reference_hold_steps.to(device=env.device, dtype=torch.int64).reshape(B).clone()
+        keys_in = state.PRNGKey
+        if keys_in.dtype is not torch.int64 or keys_in.device != env.device or not keys_in.is_contiguous():
+            keys_in = keys_in.to(device=env.device, dtype=torch.int64).contiguous()
+        hold_in = reference_hold_steps
+        if hold_in.dtype is not torch.int64 or hold_in.device != env.device or not hold_in.is_contiguous():
+            hold_in = hold_in.to(device=env.device, dtype=torch.int64).contiguous()
+        hold_in = hold_in.view(B)
+        # outputs: one allocation per element type; the kernel writes every environment (redrawn or carried over)
+        al = 16 // old_refs[0].element_size()
+        Bp = (B + al - 1) // al * al
+        new_refs = torch.empty((len(idx), Bp), dtype=env.dtype, device=env.device)[:, :B].unbind(0)
+        ibuf = torch.empty(3 * B, dtype=torch.int64, device=env.device)
+        keys, hold = ibuf[:2 * B].view(B, 2), ibuf[2 * B:]
         props, _keep = env._props_for(env.env_properties, B)
-        _native.update_ref(env.ENV_ID, env.dtype, B, props, idx, new_refs, keys, hold, self.ref_params["hold_steps_min"],
-                           self.ref_params["hold_steps_max"])
+        _native.update_ref_to(env.ENV_ID, env.dtype, B, props, idx, old_refs, keys_in, hold_in, new_refs, keys, hold,
+                              self.ref_params["hold_steps_min"], self.ref_params["hold_steps_max"])
         ref = {n: getattr(state.reference, n) for n in env.STATE_FIELDS}
         ref.update(dict(zip(self.control_state, new_refs)))
         state = replace(state, reference=env.PhysicalState(**ref), PRNGKey=keys)

@@ -250,6 +250,14 @@ int excenv_update_ref(int env, int dtype, int64_t B, const excenv_props_t* props
                       const int32_t* control_idx, void* const* reference, int64_t* keys, int64_t* hold,
                       int32_t hold_steps_min, int32_t hold_steps_max, void* stream);
 
+/* Out-of-place form of excenv_update_ref (the functional contract of GymWrapper.update_ref, gym_wrapper.py:170-175: the
+ * incoming state is not modified): reads reference_in / keys_in / hold_in, writes every environment's values — redrawn or
+ * carried over — to reference_out / keys_out / hold_out. Outputs must not alias the inputs. */
+int excenv_update_ref_to(int env, int dtype, int64_t B, const excenv_props_t* props, int32_t n_control,
+                         const int32_t* control_idx, const void* const* reference_in, const int64_t* keys_in,
+                         const int64_t* hold_in, void* const* reference_out, int64_t* keys_out, int64_t* hold_out,
+                         int32_t hold_steps_min, int32_t hold_steps_max, void* stream);
+
 /* ---- replaces CoreEnvironment.vmap_init_state(rng) (core_env.py:649-662) with one key per environment: the random branch
  * of each environment's init_state (e.g. pendulum_env.py:270-276, PMSM pmsm_env.py:402-456) — state_out[S][B] physical state
  * leaves, key_leaf [B][2] the keys that become State.PRNGKey. Same samplers as excenv_update_ref. */

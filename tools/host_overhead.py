@@ -78,6 +78,19 @@ for name in ("PENDULUM", "PMSM"):
         gw.step(act)
     torch.cuda.synchronize()
     print(f"{name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per GymWrapper.step (fused gym kernel, B=1024)")
+    from exciting_environments_amd import random as jr
+    ctl = ["theta"] if name == "PENDULUM" else ["i_d", "i_q"]
+    env_c = getattr(EnvironmentRegistry, name).make(batch_size=1024, device="cuda:0", control_state=ctl)
+    gw = GymWrapper(env_c, control_state=ctl)
+    gw.reset(rng_env=jr.split(jr.PRNGKey(1), 1024).cuda(), rng_ref=jr.PRNGKey(2).cuda())
+    for _ in range(50):
+        gw.step(act)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        gw.step(act)
+    torch.cuda.synchronize()
+    print(f"{name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per GymWrapper.step with the key-stream reference generator armed")
 
 env = EnvironmentRegistry.PENDULUM.make(batch_size=1024, device="cuda:0")
 _, state = env.vmap_reset()
