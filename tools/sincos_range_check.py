@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "exciting-environments_amd")]
 import numpy as np, torch
 from exciting_environments_amd import _native
-for lo, hi in ((0, 4), (4, 50), (50, 128), (128, 512), (512, 1024), (1024, 1e5)):
+for lo, hi in ((0, 4), (4, 50), (50, 128), (128, 512), (512, 1024), (1024, 65536), (65536, 1e6)):
     x = torch.empty(4_000_000, dtype=torch.float32).uniform_(lo, hi)
     x = torch.cat([x, -x]).cuda()
     for which, fn in ((0, np.sin), (1, np.cos)):
