@@ -650,3 +650,30 @@ def test_control_columns_with_the_vectorised_kernels_equal_the_general_kernel(B,
         env.traj_layout = "tiled"
         obs_t, _, _ = env.vmap_sim_ahead(st, acts, env.tau, env.tau)
         assert torch.equal(obs_t.reshape(B, K + 1, 10), obs_g)
+
+
+@pytest.mark.parametrize("env_name", ["pendulum", "acrobot", "cartpole"])
+@pytest.mark.parametrize("solver", ["euler", "tsit5"])
+def test_unwrapped_angles_far_outside_the_principal_range(env_name, solver):
+    """sim_ahead (SEM_AHEAD) integrates the RAW angle: it is wrapped only in the saved rows (pendulum_env.py:243-259), so a long
+    trajectory — or a caller's unwrapped initial state — feeds sin / cos with |x| of tens of thousands. The fp32 kernels serve
+    that range from their fast path (|x| <= 65 536, <= 1e-7 absolute) and the library beyond: both against the fp32 oracle."""
+    B, K = 1024, 48
+    env, props, keep, spec = make_env(env_name, B, torch.float32, solver)
+    st = random_state(env_name, B, np.float32, spec, seed=901)
+    rng = np.random.default_rng(902)
+    big = np.concatenate([rng.uniform(-6.0e4, 6.0e4, B - 64), rng.uniform(-3.0e5, 3.0e5, 64)]).astype(np.float32)
+    angle = {"pendulum": "theta", "acrobot": "theta_1", "cartpole": "theta"}[env_name]
+    st[list(oracle.STATE_FIELDS[env_name]).index(angle)] = big
+    acts = rng.uniform(-1, 1, (B, K, 1)).astype(np.float32)
+    obs, states, last = env.vmap_sim_ahead(to_state(env, st), torch.as_tensor(acts, device=env.device), env.tau, env.tau)
+    o_ref, s_ref, _ = oracle.sim_ahead(env_name, solver, st, acts, props, spec["tau"], semantics=oracle.SEM_AHEAD)
+    got, want = obs.cpu().numpy(), o_ref
+    assert np.isfinite(got).all()
+    # the rows are wrapped from angles of magnitude 1e4..3e5 (fp32 spacing up to 0.03 rad): identical wrap on both sides, and
+    # the velocities differ only through sin / cos (1e-7 absolute per evaluation, amplified by the dynamics over 48 steps)
+    err = np.abs(got - want)
+    cols = ANGLE_OBS.get(env_name, [])
+    for c in cols:  # normalised angles: compare on the circle
+        err[..., c] = np.minimum(err[..., c], 2.0 - err[..., c])
+    assert float(err.max()) <= 2e-4, float(err.max())
