@@ -761,7 +761,7 @@ class CoreEnvironment(ABC):
                 f"(floating-point floor); returning the intended {K * sub + 1} rows", RuntimeWarning)
         return sub
 
-    def _run_sim_ahead(self, init_state, actions, env_properties, obs_stepsize, action_stepsize, B, want_gym=False):
+    def _run_sim_ahead(self, init_state, actions, env_properties, obs_stepsize, action_stepsize, B, want_gym=False, out=None):
         S, A, OW = self.physical_state_dim, self.action_dim, self._obs_dim()
         actions = torch.as_tensor(actions)
         K = actions.shape[-2]
@@ -787,7 +787,9 @@ class CoreEnvironment(ABC):
         want_states = self.store_state_trajectory
         if self.traj_layout == "lane_major" and not want_gym and B > 0 and self.device.type == "cuda":
             return self._run_sim_ahead_lane_major(init_state, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub,
-                                                  want_states)
+                                                  want_states, out)
+        if out is not None:
+            raise ValueError("vmap_sim_ahead(out=...) is available for the default lane-major trajectories without gym outputs")
         if self.traj_layout == "lane_major":
             obs_buf = torch.empty((N + 1, OW, B), dtype=self.dtype, device=self.device)
             st_buf = [torch.empty((N + 1, B), dtype=self.dtype, device=self.device) for _ in range(S)] if want_states else None
@@ -851,7 +853,7 @@ class CoreEnvironment(ABC):
     _SHARED_TRAJ_BYTES = 32 << 20
 
     def _run_sim_ahead_lane_major(self, init_state, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub,
-                                  want_states):
+                                  want_states, out=None):
         """The default layout without gym outputs: buffers carved from one or two allocations, pointers computed from the base
         address, one ctypes call with plain arguments (same launch as the general path below)."""
         S, OW = self.physical_state_dim, self._obs_dim()
@@ -878,7 +880,30 @@ class CoreEnvironment(ABC):
         shared = (traj_e + S * last_e + ws_e) * isz <= self._SHARED_TRAJ_BYTES
         st_views = None
         ws_ptr = None
-        if shared:
+        if out is not None:
+            # the caller hands back what an earlier call of the same shape returned: same buffers, no allocation
+            observations, o_states, o_last = out
+            ok = (isinstance(observations, torch.Tensor) and observations.dtype is dt and observations.device == dev
+                  and tuple(observations.shape) == (B, rows, OW) and tuple(observations.stride()) == (1, OW * B, B))
+            last = tuple(getattr(o_last.physical_state, n) for n in self.STATE_FIELDS)
+            ok = ok and all(isinstance(t, torch.Tensor) and t.dtype is dt and t.device == dev and tuple(t.shape) == (B,)
+                            and t.is_contiguous() for t in last)
+            if want_states:
+                ok = ok and o_states is not None
+                st_views = tuple(getattr(o_states.physical_state, n) for n in self.STATE_FIELDS) if ok else None
+                ok = ok and all(isinstance(t, torch.Tensor) and t.dtype is dt and t.device == dev
+                                and tuple(t.shape) == (B, rows) and tuple(t.stride()) == (1, B) for t in st_views)
+            if not ok:
+                raise ValueError("vmap_sim_ahead(out=...): pass the (observations, states, last_state) an earlier call with the "
+                                 "same batch, horizon, layout and dtype returned")
+            obs_ptr = observations.data_ptr()
+            if want_states:
+                traj_ptrs = _native._ptrs(st_views)
+            last_ptrs = _native._ptrs(last)
+            if ws_e:
+                ws = torch.empty(ws_e, dtype=dt, device=dev)
+                ws_ptr = ws.data_ptr()
+        elif shared:
             buf = torch.empty(traj_e + S * last_e + ws_e, dtype=dt, device=dev)
             base = buf.data_ptr()
             if ws_e:
@@ -957,14 +982,18 @@ class CoreEnvironment(ABC):
             **{n: t.reshape(()) for n, t in zip(self.STATE_FIELDS, last)}), additions=self._additions((), True))
         return obs[0], states, last_state
 
-    def vmap_sim_ahead(self, init_state, actions, obs_stepsize, action_stepsize, return_rew_trunc_term=False):
+    def vmap_sim_ahead(self, init_state, actions, obs_stepsize, action_stepsize, return_rew_trunc_term=False, out=None):
         """Trajectories of all batch_size environments in one persistent kernel launch (core_env.py:571-616):
         actions (batch_size, n_action_steps, action_dim) -> observations (batch_size, n+1, obs_dim), states with
         leaves (batch_size, n+1), last_state with leaves (batch_size,).
 
         return_rew_trunc_term=True (extension): the same launch also evaluates what
         vmap_generate_rew_trunc_term_ahead(states, actions) would (core_env.py:618-647) and the call returns
-        (observations, states, last_state, reward [B,n,1], truncated [B,n+1,TW], terminated [B,n,1])."""
+        (observations, states, last_state, reward [B,n,1], truncated [B,n+1,TW], terminated [B,n,1]).
+
+        out=(observations, states, last_state) (extension, SURVEY.md §8b "caller-provided via an explicit out="): the triple an
+        earlier call of the same shape returned is written again instead of allocating — for chained chunks of a long run
+        (`out=prev` with `init_state=prev[2]` is allowed: last_state may alias the initial state)."""
         assert (
             obs_stepsize <= action_stepsize
         ), "The action stepsize should be greater or equal to the observation stepsize."
@@ -985,11 +1014,13 @@ class CoreEnvironment(ABC):
         B = self.batch_size
         gym_out = None
         if return_rew_trunc_term:
+            if out is not None:
+                raise ValueError("vmap_sim_ahead: out= cannot be combined with return_rew_trunc_term")
             obs, st_views, last, N, gym_out = self._run_sim_ahead(init_state, actions, self.env_properties, obs_stepsize,
                                                                   action_stepsize, B, want_gym=True)
         else:
             obs, st_views, last, N = self._run_sim_ahead(init_state, actions, self.env_properties, obs_stepsize,
-                                                         action_stepsize, B)
+                                                         action_stepsize, B, out=out)
         if st_views is None:
             states = None
         elif self.traj_layout == "tiled":

@@ -157,3 +157,29 @@ def test_sim_ahead_single_allocation_outputs_equal_separately_allocated_ones(act
     torch.cuda.synchronize()
     assert torch.equal(obs1, keep[0]) and torch.equal(st1.physical_state.i_q, keep[1])
     assert torch.equal(last1.physical_state.epsilon, keep[2])
+
+
+def test_sim_ahead_out_reuses_the_callers_buffers_across_chained_chunks():
+    """vmap_sim_ahead(out=prev): the triple of an earlier call is written again (no allocation), also when the initial state IS
+    that triple's last_state (in-place chaining of chunks, core_env.py:484-486 continuation); same values as fresh calls."""
+    env, state, _ = _env("PMSM")
+    K = 16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    chunks = [env.new_actions_buffer(K).copy_(torch.rand((B, K, 2), generator=g, device="cuda") * 2 - 1) for _ in range(4)]
+    fresh, s = [], state
+    for a in chunks:
+        o, st, s = env.vmap_sim_ahead(s, a, env.tau, env.tau)
+        fresh.append((o.clone(), st.physical_state.i_q.clone(), s.physical_state.epsilon.clone()))
+    prev = env.vmap_sim_ahead(state, chunks[0], env.tau, env.tau)
+    ptr = (prev[0].data_ptr(), prev[1].physical_state.i_q.data_ptr(), prev[2].physical_state.epsilon.data_ptr())
+    for k in range(1, 4):
+        prev = env.vmap_sim_ahead(prev[2], chunks[k], env.tau, env.tau, out=prev)
+        assert (prev[0].data_ptr(), prev[1].physical_state.i_q.data_ptr(), prev[2].physical_state.epsilon.data_ptr()) == ptr
+        assert torch.equal(prev[0], fresh[k][0]) and torch.equal(prev[1].physical_state.i_q, fresh[k][1])
+        assert torch.equal(prev[2].physical_state.epsilon, fresh[k][2])
+    other = env.vmap_sim_ahead(state, env.new_actions_buffer(K + 1).zero_(), env.tau, env.tau)
+    with pytest.raises(ValueError, match="out="):
+        env.vmap_sim_ahead(state, chunks[0], env.tau, env.tau, out=other)
+    with pytest.raises(ValueError, match="out="):
+        env.vmap_sim_ahead(state, chunks[0], env.tau, env.tau, out=prev, return_rew_trunc_term=True)
