@@ -183,3 +183,44 @@ def test_sim_ahead_out_reuses_the_callers_buffers_across_chained_chunks():
         env.vmap_sim_ahead(state, chunks[0], env.tau, env.tau, out=other)
     with pytest.raises(ValueError, match="out="):
         env.vmap_sim_ahead(state, chunks[0], env.tau, env.tau, out=prev, return_rew_trunc_term=True)
+
+
+def test_recycling_fuzz_against_a_run_that_never_recycles():
+    """Random hold / drop pattern over 600 steps: outputs (observation, state, one leaf, a view of a leaf) are kept for random
+    lifetimes and must still hold, at the end of their lifetime, the values a never-recycling twin produced for that step."""
+    import random
+
+    env, s, acts = _env("CART_POLE")
+    twin, s2, _ = _env("CART_POLE")
+    twin._slot_is_free = lambda *a, **k: False  # every pool is used once
+    rnd = random.Random(1234)
+    held = {}  # step -> (expiry, kind, object)
+    truth = {}
+    recycled, seen = 0, set()
+    for k in range(600):
+        a = acts[k % 400]
+        o, s = env.vmap_step(s, a)
+        o2, s2 = twin.vmap_step(s2, a)
+        recycled += o.data_ptr() in seen
+        seen.add(o.data_ptr())
+        if rnd.random() < 0.3:
+            kind = rnd.choice(["obs", "state", "leaf", "view"])
+            obj = {"obs": o, "state": s, "leaf": s.physical_state.omega, "view": s.physical_state.theta[5:40]}[kind]
+            held[k] = (k + rnd.randint(1, 60), kind, obj)
+            truth[k] = (o2.clone(), s2.physical_state.omega.clone(), s2.physical_state.theta.clone())
+        for j in [j for j, (exp, _, _) in held.items() if exp <= k]:
+            _, kind, obj = held.pop(j)
+            t_obs, t_omega, t_theta = truth.pop(j)
+            if kind == "obs":
+                assert torch.equal(obj, t_obs), (j, k)
+            elif kind == "state":
+                assert torch.equal(obj.physical_state.omega, t_omega) and torch.equal(obj.physical_state.theta, t_theta), (j, k)
+            elif kind == "leaf":
+                assert torch.equal(obj, t_omega), (j, k)
+            else:
+                assert torch.equal(obj, t_theta[5:40]), (j, k)
+            del obj
+        del o, o2
+    torch.cuda.synchronize()
+    assert torch.equal(s.physical_state.theta, s2.physical_state.theta)
+    assert recycled > 100, recycled  # the loop did run on recycled buffers most of the time
