@@ -294,6 +294,22 @@ int excenv_state_from_observation(int env, int dtype, int64_t B, const excenv_pr
   return t->from_obs(fc);
 }
 
+int excenv_observe(int env, int dtype, int64_t B, const excenv_props_t* props, const excenv_control_t* control,
+                   const void* const* state, void* obs, void* stream) {
+  if (int rc = check_common("excenv_observe", env, 0, dtype, B)) return rc;
+  if (!props || !state || !obs) { set_error("excenv_observe: NULL argument"); return EXCENV_ENULL; }
+  if (control) {
+    if (control->n_control < 0 || control->n_control > EXCENV_MAX_CONTROL) { set_error("excenv_observe: bad n_control %d", control->n_control); return EXCENV_EINVAL; }
+    for (int j = 0; j < control->n_control; ++j)
+      if (control->control_idx[j] < 0 || control->control_idx[j] >= table_public(env)->S) { set_error("excenv_observe: control_idx[%d] out of range", j); return EXCENV_EINVAL; }
+  }
+  int trc;
+  const EnvVTable* t = table_for(env, props, &trc);
+  if (!t) return trc;
+  ObserveCall oc{dtype, B, props, control, state, obs, (hipStream_t)stream};
+  return t->observe(oc);
+}
+
 int excenv_update_ref(int env, int dtype, int64_t B, const excenv_props_t* props, int32_t n_control,
                       const int32_t* control_idx, void* const* reference, int64_t* keys, int64_t* hold,
                       int32_t hold_steps_min, int32_t hold_steps_max, void* stream) {

@@ -693,6 +693,47 @@ template <class M, typename T> __global__ void __launch_bounds__(BLOCK) from_obs
   }
 }
 
+// ---- generate_observation on a batch of states (e.g. pendulum_env.py:311-329, PMSM pmsm_env.py:898-919) ----------------------
+// obs[i] = M::observe(state i) followed by the normalised reference of every controlled field: the same device function the
+// step and trajectory kernels fuse, as a launch of its own (vmap_reset, user code that builds states by hand).
+template <typename T, class M> struct ObserveArgs {
+  KProps<T, M> kp;
+  int64_t B;
+  int32_t n_control;
+  int32_t control_idx[EXCENV_MAX_CONTROL];
+  const T* state[M::S];
+  const T* reference[EXCENV_MAX_CONTROL];
+  T* obs;
+};
+
+template <class M, typename T> __global__ void __launch_bounds__(BLOCK) observe_kernel(const ObserveArgs<T, M> ka) {
+  constexpr int S = M::S, O = M::O;
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= ka.B) return;
+  Ctx<T, M> c;
+  load_ctx<true, T, M, false>(c, ka.kp, i, T(0), T(0), T(0));
+  T st[S], ob[O];
+#pragma unroll
+  for (int j = 0; j < S; ++j) st[j] = ka.state[j][i];
+  M::observe(st, c, ob);
+  T* row = ka.obs + i * (O + ka.n_control);
+#pragma unroll
+  for (int j = 0; j < O; ++j) row[j] = ob[j];
+#pragma unroll
+  for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+    if (j < ka.n_control) {
+      const int f = ka.control_idx[j];
+      T lo = c.smin[0], hi = c.smax[0];
+#pragma unroll
+      for (int q = 1; q < S; ++q) {
+        lo = (f == q) ? c.smin[q] : lo;
+        hi = (f == q) ? c.smax[q] : hi;
+      }
+      row[O + j] = normalize(ka.reference[j][i], lo, hi);
+    }
+  }
+}
+
 // ---- probes for the in-kernel math (tests) ---------------------------------------------------
 template <typename T> __global__ void probe_kernel(int which, int64_t n, const T* in, T* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

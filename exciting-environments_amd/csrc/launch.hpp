@@ -88,6 +88,16 @@ struct FromObsCall {
   hipStream_t stream;
 };
 
+struct ObserveCall {
+  int dtype;
+  int64_t B;
+  const excenv_props_t* props;
+  const excenv_control_t* control;
+  const void* const* state;
+  void* obs;
+  hipStream_t stream;
+};
+
 struct RefGenCall {
   int dtype;
   int64_t B;
@@ -123,6 +133,7 @@ struct EnvVTable {
   int (*from_obs)(const FromObsCall&);
   int (*update_ref)(const RefGenCall&);
   int (*random_state)(const RandomStateCall&);
+  int (*observe)(const ObserveCall&);
 };
 
 template <typename T, class M>
@@ -586,6 +597,27 @@ template <class M, typename T> static int launch_from_obs(const FromObsCall& fc)
   return check_launch("excenv_state_from_observation");
 }
 
+template <class M, typename T> static int launch_observe(const ObserveCall& oc) {
+  ObserveArgs<T, M> ka;
+  std::memset(&ka, 0, sizeof(ka));
+  fill_props<T, M>(ka.kp, oc.props);
+  ka.B = oc.B;
+  ka.n_control = oc.control ? oc.control->n_control : 0;
+  ka.obs = (T*)oc.obs;
+  for (int j = 0; j < M::S; ++j) {
+    if (!oc.state[j]) { set_error("excenv_observe: state pointer %d is NULL", j); return EXCENV_ENULL; }
+    ka.state[j] = (const T*)oc.state[j];
+  }
+  for (int j = 0; j < ka.n_control; ++j) {
+    if (!oc.control->reference[j]) { set_error("excenv_observe: reference pointer %d is NULL", j); return EXCENV_ENULL; }
+    ka.control_idx[j] = oc.control->control_idx[j];
+    ka.reference[j] = (const T*)oc.control->reference[j];
+  }
+  if (oc.B == 0) return EXCENV_OK;
+  hipLaunchKernelGGL((observe_kernel<M, T>), dim3((unsigned)((oc.B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, oc.stream, ka);
+  return check_launch("excenv_observe");
+}
+
 template <class M, typename T> static int launch_update_ref(const RefGenCall& rc) {
   RefGenArgs<T, M> ka;
   std::memset(&ka, 0, sizeof(ka));
@@ -645,9 +677,12 @@ template <template <typename> class MT> struct EnvEntry {
   static int random_state(const RandomStateCall& rc) {
     return rc.dtype == EXCENV_F32 ? launch_random_state<MT<float>, float>(rc) : launch_random_state<MT<double>, double>(rc);
   }
+  static int observe(const ObserveCall& oc) {
+    return oc.dtype == EXCENV_F32 ? launch_observe<MT<float>, float>(oc) : launch_observe<MT<double>, double>(oc);
+  }
   static EnvVTable vtable() {
     return EnvVTable{MT<float>::S, MT<float>::A, MT<float>::O, MT<float>::P, &step, &sim, &traj_gym, &from_obs, &update_ref,
-                     &random_state};
+                     &random_state, &observe};
   }
 };
 

@@ -91,7 +91,7 @@ def lib():
         l.excenv_truncated_width.restype = ctypes.c_int32
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
                    "excenv_probe_math", "excenv_probe_div", "excenv_rew_trunc_term", "excenv_state_from_observation",
-                   "excenv_update_ref", "excenv_update_ref_to", "excenv_random_state"):
+                   "excenv_update_ref", "excenv_update_ref_to", "excenv_random_state", "excenv_observe"):
             getattr(l, fn).restype = ctypes.c_int
         vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
         # typed prototypes: plain Python ints / floats / None / byref() pass without per-call ctypes wrapping
@@ -335,6 +335,16 @@ def update_ref(env_id, dtype, B, props: Props, control_idx: Sequence[int], refer
             ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(hold.data_ptr()), ctypes.c_int32(hold_min), ctypes.c_int32(hold_max),
             ctypes.c_void_p(_raw_stream(keys.device)))
     _check(rc, "excenv_update_ref")
+
+
+def observe(env_id, dtype, B, props: Props, control: Optional[Control], state: Sequence[torch.Tensor], obs: torch.Tensor):
+    """excenv_observe: generate_observation for a batch of states in one launch (obs: [B, O + n_control] row-major)."""
+    _require_device(obs, "generate_observation")
+    with _on_device(obs.device):
+        rc = lib().excenv_observe(ctypes.c_int(env_id), ctypes.c_int(dtype_id(dtype)), ctypes.c_int64(B), ctypes.byref(props),
+                                  ctypes.byref(control) if control is not None else None, _ptrs(state),
+                                  ctypes.c_void_p(obs.data_ptr()), ctypes.c_void_p(_raw_stream(obs.device)))
+    _check(rc, "excenv_observe")
 
 
 def update_ref_to(env_id, dtype, B, props: Props, control_idx: Sequence[int], reference_in: Sequence[torch.Tensor],

@@ -324,9 +324,37 @@ class CoreEnvironment(ABC):
         """core_env.py:649-662."""
         return self._init_state(self.env_properties, rng, (self.batch_size,))
 
+    def _observe_device(self, state, env_properties):
+        if self.device.type != "cuda":
+            return None
+        leaves = [getattr(state.physical_state, n) for n in self.STATE_FIELDS]
+        l0 = leaves[0]
+        if not (isinstance(l0, torch.Tensor) and l0.is_cuda and l0.ndim == 1 and l0.shape[0] > 0):
+            return None
+        B = l0.shape[0]
+        if not all(isinstance(l, torch.Tensor) and l.ndim == 1 and l.shape[0] == B for l in leaves):
+            return None
+        try:
+            props, _keep = self._props_for(env_properties, B)
+        except (ValueError, AssertionError, RuntimeError):
+            return None  # properties shaped for something else than a [B] batch (e.g. lifted for trajectories)
+        st = [self._t(l, (B,)) for l in leaves]
+        control = None
+        if self.control_state:
+            refs = [self._t(getattr(state.reference, n), (B,)) for n in self.control_state]
+            control = _native.make_control([self.STATE_FIELDS.index(n) for n in self.control_state], refs)
+        obs = torch.empty((B, self._obs_dim()), dtype=self.dtype, device=self.device)
+        _native.observe(self.ENV_ID, self.dtype, B, props, control, st, obs)
+        return obs
+
     def generate_observation(self, state, env_properties):
         """Normalised physical state (+ normalised reference for each name in control_state), stacked on the last
-        axis (e.g. pendulum_env.py:311-329). Elementwise torch ops; the step kernels fuse their own copy."""
+        axis (e.g. pendulum_env.py:311-329). A batch of states on the HIP device ([B] leaves) is one launch (excenv_observe, the
+        device function the step kernels fuse); anything else (a single environment, trajectories, CPU tensors) goes through the
+        elementwise torch twin below."""
+        dev = self._observe_device(state, env_properties)
+        if dev is not None:
+            return dev
         ns = self.normalize_state(state, env_properties)
         cols = [getattr(ns.physical_state, n) for n in self.STATE_FIELDS]
         cols += [getattr(ns.reference, n) for n in self.control_state]

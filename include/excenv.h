@@ -250,6 +250,13 @@ int excenv_update_ref(int env, int dtype, int64_t B, const excenv_props_t* props
                       const int32_t* control_idx, void* const* reference, int64_t* keys, int64_t* hold,
                       int32_t hold_steps_min, int32_t hold_steps_max, void* stream);
 
+/* ---- replaces CoreEnvironment.generate_observation vmapped over the batch (e.g. pendulum_env.py:311-329, PMSM
+ * pmsm_env.py:898-919; used by vmap_reset, core_env.py:665-687): obs [B][O + n_control] row-major = the normalised physical
+ * state in the environment's observation order followed by the normalised reference of each controlled field
+ * (control->reference[j], NaN allowed). The same device function the step / trajectory kernels fuse. */
+int excenv_observe(int env, int dtype, int64_t B, const excenv_props_t* props, const excenv_control_t* control,
+                   const void* const* state, void* obs, void* stream);
+
 /* Out-of-place form of excenv_update_ref (the functional contract of GymWrapper.update_ref, gym_wrapper.py:170-175: the
  * incoming state is not modified): reads reference_in / keys_in / hold_in, writes every environment's values — redrawn or
  * carried over — to reference_out / keys_out / hold_out. Outputs must not alias the inputs. */

@@ -336,3 +336,48 @@ def test_random_state_kernel_equals_the_host_twin(reg, dtype):
     # CPU keys on a device environment take the same kernel
     s_g2 = env.vmap_init_state(keys)
     assert torch.equal(s_g2.PRNGKey, s_g.PRNGKey) and torch.equal(getattr(s_g2.physical_state, env.STATE_FIELDS[0]), getattr(s_g.physical_state, env.STATE_FIELDS[0]))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("reg", list(excenvs.EnvironmentRegistry), ids=lambda r: r.name.lower())
+def test_generate_observation_kernel_equals_the_torch_twin(reg, dtype):
+    """excenv_observe (generate_observation of a [B] batch on the device, one launch) against the elementwise torch twin the
+    CPU environments use: identical arithmetic for the normalised fields (bit-equal), sin / cos of the PMSM angle to 2 ulp;
+    controlled-reference columns incl. NaN references; a per-environment property array."""
+    from dataclasses import replace
+
+    B = 777
+    ctl = {"PMSM": ["i_d", "torque"], "PENDULUM": ["theta"], "ACROBOT": ["theta_2", "omega_1"]}.get(reg.name, [])
+    pn = None
+    if reg.name == "MASS_SPRING_DAMPER":  # a batched normalisation bound
+        pn = {"deflection": excenvs.MinMaxNormalization(min=-10 * np.ones(B), max=np.linspace(5, 15, B)),
+              "velocity": excenvs.MinMaxNormalization(min=-10, max=10)}
+    kw = dict(batch_size=B, dtype=dtype, control_state=ctl)
+    if pn is not None:
+        kw["physical_normalizations"] = pn
+    env = reg.make(device="cuda", **kw)
+    cpu = reg.make(device="cpu", **kw)
+    g = torch.Generator().manual_seed(21)
+    _, st = cpu.vmap_reset()
+    phys = {n: (torch.rand(B, generator=g, dtype=dtype) - 0.5) * 6 for n in cpu.STATE_FIELDS}
+    ref = {n: torch.full((B,), float("nan"), dtype=dtype) for n in cpu.STATE_FIELDS}
+    for n in ctl:
+        ref[n] = (torch.rand(B, generator=g, dtype=dtype) - 0.5) * 4
+        ref[n][::7] = float("nan")
+    st = replace(st, physical_state=cpu.PhysicalState(**phys), reference=cpu.PhysicalState(**ref))
+    want = cpu.generate_observation(st, cpu.env_properties)
+    st_g = replace(st, physical_state=env.PhysicalState(**{n: v.cuda() for n, v in phys.items()}),
+                   reference=env.PhysicalState(**{n: v.cuda() for n, v in ref.items()}))
+    got = env.generate_observation(st_g, env.env_properties).cpu()
+    assert got.shape == want.shape == (B, len(env.obs_description)) and got.dtype == want.dtype
+    if reg.name == "PMSM":
+        tol = 3e-7 if dtype == torch.float32 else 1e-15
+        # fp32: the twin folds (max - min) of the Python-float bounds in double (like the reference's static PMSM properties),
+        # the kernels subtract the fp32 bounds: one ulp of the denominator for bounds such as 2 * 400 / 3
+        assert torch.allclose(got, want, rtol=0, atol=tol, equal_nan=True), float((got - want).abs().nan_to_num().max())
+    else:
+        assert torch.equal(got.nan_to_num(7.0), want.nan_to_num(7.0)), float((got - want).abs().nan_to_num().max())
+    # vmap_reset goes through the same launch
+    obs_r, st_r = env.vmap_reset()
+    obs_c, _ = cpu.vmap_reset()
+    assert torch.allclose(obs_r.cpu(), obs_c, rtol=0, atol=3e-7, equal_nan=True)
