@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define EXCENV_ABI_VERSION 3
+/* 4: v3 + excenv_random_state, excenv_update_ref_to, excenv_observe (additions only; every v3 signature is unchanged) */
+#define EXCENV_ABI_VERSION 4
 
 /* Environment ids. Field orders follow the reference dataclasses. */
 typedef enum {
