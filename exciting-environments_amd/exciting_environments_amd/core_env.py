@@ -689,6 +689,34 @@ class CoreEnvironment(ABC):
         """reward == 0 (e.g. pendulum_env.py:387-390)."""
         return reward == 0
 
+    def repeat_values(self, x, n_repeat):
+        """core_env.py:279-290: repeats the values of x n_repeat times (None / tuple / tensor / float / bool)."""
+        if x is None:
+            return None
+        if isinstance(x, tuple):
+            return tuple(self.repeat_values(i, n_repeat) for i in x)
+        if isinstance(x, torch.Tensor):
+            return x.expand((n_repeat,) + tuple(x.shape)).clone() if x.ndim else torch.full((n_repeat,), x.item(), dtype=x.dtype, device=x.device)
+        if isinstance(x, (float, bool)):
+            return torch.full((n_repeat,), x, dtype=torch.bool if isinstance(x, bool) else self.dtype, device=self.device)
+        raise ValueError(f"State needs to consist of jnp.array, tuple, float or bool, but {type(x)} is given.")
+
+    def generate_rew_trunc_term_ahead(self, states, actions, env_properties):
+        """core_env.py:490-531 for the trajectory of ONE environment returned by `sim_ahead`: reward [n,1] on rows 1..,
+        truncated [n+1,TW] on all rows, terminated [n,1] on rows 1.. (elementwise, the same per-row functions)."""
+        actions = torch.as_tensor(actions)
+        assert actions.ndim == 2, "The actions need to have two dimensions: (n_action_steps, action_dim)"
+        assert (
+            actions.shape[-1] == self.action_dim
+        ), f"The last dimension does not correspond to the action dim which is {self.action_dim}, but {actions.shape[-1]} is given"
+        cut = lambda tree: replace(tree, physical_state=self.PhysicalState(**{n: getattr(tree.physical_state, n)[1:] for n in self.STATE_FIELDS}),
+                                   reference=self.PhysicalState(**{n: getattr(tree.reference, n)[1:] for n in self.STATE_FIELDS}))
+        tail = cut(states)
+        reward = self.generate_reward(tail, None, env_properties)
+        truncated = self.generate_truncated(states, env_properties)
+        terminated = self.generate_terminated(tail, reward, env_properties)
+        return reward, truncated, terminated
+
     def vmap_generate_rew_trunc_term_ahead(self, states, actions):
         """core_env.py:618-647 / :490-531 for trajectories returned by vmap_sim_ahead: reward [B,K,1] on rows 1..,
         truncated [B,K+1,TW] on all rows, terminated [B,K,1] on rows 1... One HIP launch over the stored trajectory

@@ -338,3 +338,34 @@ def test_output_slot_liveness_test_on_cpu_tensors():
     del rew
     assert env._slot_is_free(sg, 1, 0)
     assert env._slots_per_alloc(False) >= 3
+
+
+def test_single_environment_rew_trunc_term_ahead_and_repeat_values():
+    """core_env.py:490-531 (single-environment form) agrees with row b of the vmapped form; repeat_values (core_env.py:279-290)."""
+    import torch
+    from dataclasses import replace
+    from exciting_environments_amd import EnvironmentRegistry
+
+    B, K = 3, 6
+    env = EnvironmentRegistry.PENDULUM.make(batch_size=B, device="cpu", control_state=["theta"])
+    g = torch.Generator().manual_seed(3)
+    phys = env.PhysicalState(theta=(torch.rand((B, K + 1), generator=g) - 0.5) * 6, omega=(torch.rand((B, K + 1), generator=g) - 0.5) * 30)
+    ref = env.PhysicalState(theta=(torch.rand((B, K + 1), generator=g) - 0.5) * 6, omega=torch.full((B, K + 1), float("nan")))
+    _, st = env.vmap_reset()
+    states = replace(st, physical_state=phys, reference=ref)
+    acts = torch.zeros((B, K, 1))
+    rew, trunc, term = env.vmap_generate_rew_trunc_term_ahead(states, acts)
+    assert rew.shape == (B, K, 1) and trunc.shape[:2] == (B, K + 1) and term.shape == (B, K, 1)
+    for b in range(B):
+        one = replace(st, physical_state=env.PhysicalState(theta=phys.theta[b], omega=phys.omega[b]),
+                      reference=env.PhysicalState(theta=ref.theta[b], omega=ref.omega[b]))
+        r1, tr1, te1 = env.generate_rew_trunc_term_ahead(one, acts[b], env.env_properties)
+        assert torch.equal(r1, rew[b]) and torch.equal(tr1, trunc[b]) and torch.equal(te1, term[b])
+    with pytest.raises(AssertionError, match="two dimensions"):
+        env.generate_rew_trunc_term_ahead(states, acts, env.env_properties)
+    assert env.repeat_values(None, 4) is None
+    assert env.repeat_values(2.5, 3).tolist() == [2.5, 2.5, 2.5] and env.repeat_values(True, 2).tolist() == [True, True]
+    t = env.repeat_values((torch.tensor(1.0), torch.tensor([1.0, 2.0])), 2)
+    assert t[0].tolist() == [1.0, 1.0] and t[1].tolist() == [[1.0, 2.0], [1.0, 2.0]]
+    with pytest.raises(ValueError):
+        env.repeat_values("x", 2)
