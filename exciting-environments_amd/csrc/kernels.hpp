@@ -372,8 +372,8 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       aux[v].eps0 = st[v][2];
-      aux[v].buf0[0] = aux[v].prev_clip[0] = st[v][0];
-      aux[v].buf0[1] = aux[v].prev_clip[1] = st[v][1];
+      aux[v].prev_clip[0] = st[v][0];
+      aux[v].prev_clip[1] = st[v][1];
     }
   }
   const bool deadtime_on = (M::IS_PMSM) ? (c.P[M::P - 1] > T(0)) : false;
@@ -427,8 +427,8 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
         else M::post(sv[v], c);
         if constexpr (M::IS_PMSM) {  // pmsm_env.py:785-791
           if (deadtime_on) {
-            sv[v][0] = (n == 0) ? aux[v].buf0[0] : aux[v].prev_clip[0];
-            sv[v][1] = (n == 0) ? aux[v].buf0[1] : aux[v].prev_clip[1];
+            sv[v][0] = aux[v].prev_clip[0];  // row 0: still the initial buffer (prev_clip starts as it)
+            sv[v][1] = aux[v].prev_clip[1];
           } else {
             sv[v][0] = T(0);
             sv[v][1] = T(0);

@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
   AheadAux<T> aux;
   if constexpr (AHEAD && M::IS_PMSM) {
     aux.eps0 = st[2];
-    aux.buf0[0] = aux.prev_clip[0] = st[0];
-    aux.buf0[1] = aux.prev_clip[1] = st[1];
+    aux.prev_clip[0] = st[0];
+    aux.prev_clip[1] = st[1];
   }
   const bool deadtime_on = M::IS_PMSM ? (c.P[M::P - 1] > T(0)) : false;
 
@@ -104,8 +104,8 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
         M::post(sv, c);
         if constexpr (M::IS_PMSM) {
           if (deadtime_on) {
-            sv[0] = (n == 0) ? aux.buf0[0] : aux.prev_clip[0];
-            sv[1] = (n == 0) ? aux.buf0[1] : aux.prev_clip[1];
+            sv[0] = aux.prev_clip[0];  // row 0: still the initial buffer
+            sv[1] = aux.prev_clip[1];
           } else {
             sv[0] = T(0);
             sv[1] = T(0);

@@ -142,7 +142,7 @@ __device__ __forceinline__ void env_step(T (&st)[M::S], const T (&a)[M::A], cons
 
 // Extra carried values for the reference's sim_ahead structure (only PMSM needs any).
 template <typename T> struct AheadAux {
-  T eps0, buf0[2], prev_clip[2];
+  T eps0, prev_clip[2];  // prev_clip starts as the initial voltage buffer, so row 0 of the trajectory shows that buffer
 };
 
 // One solver step of the raw ODE state, reference _ode_solver_simulate_ahead structure (SEM_AHEAD):
