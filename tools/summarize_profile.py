@@ -45,7 +45,7 @@ if bench is not None:
         gbs = rf["algorithmic_bytes_per_launch"] / (hot_avg_ms[0] * 1e-3) / 1e9
         lines += [f"* rocprofv3 --kernel-trace --stats average of the dominant kernel ({hot_avg_ms[3]} calls, profiled run): "
                   f"{hot_avg_ms[0]:.4f} ms -> {gbs:.0f} GB/s algorithmic = **{gbs / 8000.0:.4f} of the 8 TB/s HBM peak** "
-                  f"(bench line, un-profiled: {rf['frac']:.4f}; profiled passes run at a slightly lower clock, MI355X_MICROARCH.md DVFS item 2)"]
+                  f"(bench line, un-profiled: {rf['frac']:.4f}; the profiled run is another process: its buffers sit elsewhere in physical memory, which moves this kernel by up to 25 %, DESIGN.md §6, and profiled passes run at a slightly lower clock)"]
     lines.append("")
 # ---- kernel stats ------------------------------------------------------------------------------
 for f in find("trace", "*kernel_stats.csv"):
