@@ -194,6 +194,10 @@ def parse_args():
     ap.add_argument("--obs-only", action="store_true", help="skip the state trajectories (not the reference's full outputs)")
     ap.add_argument("--no-workspace", action="store_true", help="env-major buffers: no transposition workspace")
     ap.add_argument("--no-fused", action="store_true", help="env-major buffers: do not use the fused LDS time-tile kernel")
+    ap.add_argument("--placement-candidates", type=int, default=3,
+                    help="sim_ahead path, lane-major trajectories: allocate this many output-buffer sets during set-up, keep the "
+                         "one a probe launch runs fastest into (physical placement moves the kernel by up to 25 %%, DESIGN.md "
+                         "§6) and write it again every step (vmap_sim_ahead(out=...)); 0: fresh allocation per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -265,6 +269,11 @@ def main():
     gatherer = ObservationGatherer(B * world) if use_gather else None
     gathered = None
 
+    # output buffers of the trajectory path: one set, chosen among a few placements, written again by every step
+    bufs, probe_ms = None, []
+    if args.path != "step" and args.placement_candidates > 0 and args.traj_layout == "lane_major":
+        bufs, probe_ms = env.new_trajectory_buffers(state, actions, env.tau, env.tau, candidates=args.placement_candidates)
+
     step_actions = [actions[:, k, :].contiguous() for k in range(min(Kc, 8))] if args.path == "step" else None
     step_count = [0]
     last_obs = [None]
@@ -281,7 +290,12 @@ def main():
             step_count[0] += 1
             last_obs[0] = obs
             return last
-        obs, states, last = env.vmap_sim_ahead(st, actions, env.tau, env.tau)
+        nonlocal bufs
+        if bufs is not None:
+            bufs = env.vmap_sim_ahead(st, actions, env.tau, env.tau, out=bufs)
+            obs, states, last = bufs
+        else:
+            obs, states, last = env.vmap_sim_ahead(st, actions, env.tau, env.tau)
         last_obs[0] = obs
         if gatherer is not None and args.gather == "chunk":
             gatherer.wait()  # previous chunk's gather must have drained before its buffer is reused
@@ -380,6 +394,10 @@ def main():
                 "collective": (gatherer.collective if gatherer is not None else None),
                 "gathered_slice_matches_local": gather_ok,
                 "outputs_finite": finite,
+                "output_buffers": ("fresh allocation per step" if bufs is None else
+                                   f"one set written again every step (vmap_sim_ahead(out=...)), chosen during set-up as the fastest "
+                                   f"of {len(probe_ms) or 1} placements; probe launch ms per placement (rank 0): "
+                                   + ", ".join(f"{t:.3f}" for t in probe_ms)),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

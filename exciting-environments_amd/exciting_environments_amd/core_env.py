@@ -1089,6 +1089,29 @@ class CoreEnvironment(ABC):
             return (obs, states, last_state) + tuple(gym_out)
         return obs, states, last_state
 
+    def new_trajectory_buffers(self, init_state, actions, obs_stepsize, action_stepsize, candidates: int = 1):
+        """Output buffers for `vmap_sim_ahead(..., out=...)`: the (observations, states, last_state) triple of a first call with
+        these inputs. With candidates > 1 that many sets are allocated side by side, one launch into each is timed (HIP events)
+        and the fastest set is kept, the others are freed: where the driver places tens of GB of trajectory buffers in physical
+        memory moves the trajectory kernel by up to 25 % (HBM write-credit stalls), and about one placement in five
+        is a slow one — a long chunked run that reuses its buffers should start on a good one. Returns (triple, probe_ms list)."""
+        sets, times = [], []
+        for _ in range(max(1, int(candidates))):
+            trip = self.vmap_sim_ahead(init_state, actions, obs_stepsize, action_stepsize)
+            if candidates > 1:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.vmap_sim_ahead(init_state, actions, obs_stepsize, action_stepsize, out=trip)  # warm (clocks, caches)
+                t0.record()
+                self.vmap_sim_ahead(init_state, actions, obs_stepsize, action_stepsize, out=trip)
+                t1.record()
+                t1.synchronize()
+                times.append(float(t0.elapsed_time(t1)))
+            sets.append(trip)
+        best = min(range(len(sets)), key=lambda i: times[i]) if times else 0
+        keep = sets[best]
+        del sets
+        return keep, times
+
     def make_stepper(self, n_steps: int = 1, graph: bool = False, gym: bool = False):
         """In-place multi-step stepping with static buffers (opt-in; see stepper.Stepper): `n_steps` chained vmap_step
         (gym=True: vmap_gym_step) launches per `run()`, eagerly with pre-built arguments or as one HIP-graph replay."""

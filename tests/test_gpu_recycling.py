@@ -224,3 +224,22 @@ def test_recycling_fuzz_against_a_run_that_never_recycles():
     torch.cuda.synchronize()
     assert torch.equal(s.physical_state.theta, s2.physical_state.theta)
     assert recycled > 100, recycled  # the loop did run on recycled buffers most of the time
+
+
+def test_new_trajectory_buffers_returns_a_reusable_triple():
+    """env.new_trajectory_buffers(..., candidates=N): the triple of a first call, chosen among N placements by a timed probe
+    launch; usable as out= and holding the same values a plain call returns."""
+    env, state, _ = _env("PENDULUM")
+    K = 20
+    acts = env.new_actions_buffer(K).uniform_(-1, 1)
+    want = env.vmap_sim_ahead(state, acts, env.tau, env.tau)
+    trip, probe = env.new_trajectory_buffers(state, acts, env.tau, env.tau, candidates=3)
+    assert len(probe) == 3 and all(t > 0 for t in probe)
+    assert torch.equal(trip[0], want[0]) and torch.equal(trip[1].physical_state.omega, want[1].physical_state.omega)
+    ptr = trip[0].data_ptr()
+    again = env.vmap_sim_ahead(trip[2], acts, env.tau, env.tau, out=trip)
+    assert again[0].data_ptr() == ptr
+    ref2 = env.vmap_sim_ahead(want[2], acts, env.tau, env.tau)
+    assert torch.equal(again[0], ref2[0]) and torch.equal(again[2].physical_state.theta, ref2[2].physical_state.theta)
+    one, probe1 = env.new_trajectory_buffers(state, acts, env.tau, env.tau)
+    assert probe1 == [] and torch.equal(one[0], want[0])
