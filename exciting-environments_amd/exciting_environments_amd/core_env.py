@@ -90,6 +90,9 @@ class CoreEnvironment(ABC):
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None and torch.cuda.is_available():
+            # "cuda" -> "cuda:<current>": tensors report an indexed device, and the fast paths compare devices for equality
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.env_properties = env_properties
         self.in_axes_env_properties = self.create_in_axes_dataclass(env_properties)
         self.action_dim = len(fields(self.Action))
@@ -939,15 +942,16 @@ class CoreEnvironment(ABC):
         if out is not None:
             # the caller hands back what an earlier call of the same shape returned: same buffers, no allocation
             observations, o_states, o_last = out
-            ok = (isinstance(observations, torch.Tensor) and observations.dtype is dt and observations.device == dev
+            on_dev = lambda t: t.device.type == dev.type and (dev.index is None or t.device.index == dev.index)
+            ok = (isinstance(observations, torch.Tensor) and observations.dtype is dt and on_dev(observations)
                   and tuple(observations.shape) == (B, rows, OW) and tuple(observations.stride()) == (1, OW * B, B))
             last = tuple(getattr(o_last.physical_state, n) for n in self.STATE_FIELDS)
-            ok = ok and all(isinstance(t, torch.Tensor) and t.dtype is dt and t.device == dev and tuple(t.shape) == (B,)
+            ok = ok and all(isinstance(t, torch.Tensor) and t.dtype is dt and on_dev(t) and tuple(t.shape) == (B,)
                             and t.is_contiguous() for t in last)
             if want_states:
                 ok = ok and o_states is not None
                 st_views = tuple(getattr(o_states.physical_state, n) for n in self.STATE_FIELDS) if ok else None
-                ok = ok and all(isinstance(t, torch.Tensor) and t.dtype is dt and t.device == dev
+                ok = ok and all(isinstance(t, torch.Tensor) and t.dtype is dt and on_dev(t)
                                 and tuple(t.shape) == (B, rows) and tuple(t.stride()) == (1, B) for t in st_views)
             if not ok:
                 raise ValueError("vmap_sim_ahead(out=...): pass the (observations, states, last_state) an earlier call with the "

@@ -187,11 +187,16 @@ def _full_length_run(env_name, solver, dtype, log2_batch, n_chunks, Kc, T, tau=N
     trig_free = env_name in ("mass_spring_damper", "fluid_tank")
     angle_cols = {"pendulum": [0], "cartpole": [2], "acrobot": [0, 1]}.get(env_name, [])
     steps = 0
+    prev = None
     for c in range(n_chunks):
         acts_small = rng.uniform(-1, 1, (T, Kc, env.action_dim)).astype(np_dt)
         actions = _tile_actions(env, acts_small, B // T)
         st0 = [getattr(state.physical_state, n)[:T].cpu().numpy() for n in env.STATE_FIELDS]
-        obs, states, last = env.vmap_sim_ahead(state, actions, env.tau, env.tau)
+        # odd chunks write the previous chunk's buffers again (out=, with the initial state aliasing its last_state), even
+        # chunks allocate: both forms of the continuation at the full size
+        reuse = prev if (c % 2 == 1 and prev is not None) else None
+        prev = env.vmap_sim_ahead(state, actions, env.tau, env.tau, out=reuse)
+        obs, states, last = prev
         assert obs.shape == (B, Kc + 1, len(env.obs_description))
         assert _all_tiles_equal(obs, T), f"chunk {c}: observation tiles differ"
         assert bool(torch.isfinite(obs[:, -1]).all()), f"chunk {c}: non-finite observations"
@@ -212,6 +217,8 @@ def _full_length_run(env_name, solver, dtype, log2_batch, n_chunks, Kc, T, tau=N
         state = last
         steps += B * Kc
         del obs, states, actions
+        if c % 2 == 1:
+            prev = None  # the next (even) chunk allocates afresh; `state` keeps last_state alive
     return steps
 
 
