@@ -1101,7 +1101,12 @@ class CoreEnvironment(ABC):
         is a slow one — a long chunked run that reuses its buffers should start on a good one. Returns (triple, probe_ms list)."""
         sets, times = [], []
         for _ in range(max(1, int(candidates))):
-            trip = self.vmap_sim_ahead(init_state, actions, obs_stepsize, action_stepsize)
+            try:
+                trip = self.vmap_sim_ahead(init_state, actions, obs_stepsize, action_stepsize)
+            except torch.OutOfMemoryError:
+                if not sets:
+                    raise
+                break  # not enough memory for another candidate next to the ones held: choose among those
             if candidates > 1:
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 self.vmap_sim_ahead(init_state, actions, obs_stepsize, action_stepsize, out=trip)  # warm (clocks, caches)
