@@ -63,6 +63,23 @@ def test_abi_argument_validation_without_gpu():
                          one, ctypes.c_void_p(16), ctypes.byref(bad), None)
     assert rc == -1 and b"envs_per_lane" in lib.excenv_last_error()
     assert not hasattr(lib, "excenv_set_tuning")
+    # the entry points added with ABI v4
+    i64, i32, vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p
+    assert lib.excenv_observe(99, 0, i64(4), ctypes.byref(p), None, one, vp(16), None) == -1
+    assert lib.excenv_observe(0, 0, i64(4), ctypes.byref(p), None, None, vp(16), None) == -2 and b"NULL" in lib.excenv_last_error()
+    ctl = _native.Control()
+    ctl.n_control = 1
+    ctl.control_idx[0] = 7  # the pendulum has two fields
+    assert lib.excenv_observe(0, 0, i64(4), ctypes.byref(p), ctypes.byref(ctl), one, vp(16), None) == -1
+    assert b"control_idx" in lib.excenv_last_error()
+    assert lib.excenv_random_state(0, 0, i64(4), ctypes.byref(p), None, one, vp(16), None) == -2
+    assert lib.excenv_random_state(0, 5, i64(4), ctypes.byref(p), vp(16), one, vp(16), None) == -1  # bad dtype
+    assert lib.excenv_update_ref_to(0, 0, i64(4), ctypes.byref(p), i32(0), None, None, vp(16), vp(32), None, vp(16), vp(32),
+                                    i32(1), i32(5), None) == -1 and b"alias" in lib.excenv_last_error()
+    assert lib.excenv_update_ref_to(0, 0, i64(4), ctypes.byref(p), i32(9), None, None, vp(16), vp(32), None, vp(48), vp(64),
+                                    i32(1), i32(5), None) == -1 and b"n_control" in lib.excenv_last_error()
+    assert lib.excenv_update_ref_to(0, 0, i64(4), ctypes.byref(p), i32(0), None, None, None, vp(32), None, vp(48), vp(64),
+                                    i32(1), i32(5), None) == -2
 
 
 @pytest.mark.parametrize("env_type", envs_to_test)
