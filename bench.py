@@ -194,10 +194,11 @@ def parse_args():
     ap.add_argument("--obs-only", action="store_true", help="skip the state trajectories (not the reference's full outputs)")
     ap.add_argument("--no-workspace", action="store_true", help="env-major buffers: no transposition workspace")
     ap.add_argument("--no-fused", action="store_true", help="env-major buffers: do not use the fused LDS time-tile kernel")
-    ap.add_argument("--placement-candidates", type=int, default=3,
-                    help="sim_ahead path, lane-major trajectories: allocate this many output-buffer sets during set-up, keep the "
+    ap.add_argument("--placement-candidates", type=int, default=0,
+                    help="0 (default): the plain API, every step allocates its outputs like the reference's functional calls. "
+                         "N > 0 (sim_ahead path, lane-major trajectories): allocate N output-buffer sets during set-up, keep the "
                          "one a probe launch runs fastest into (physical placement moves the kernel by up to 25 %%, DESIGN.md "
-                         "§6) and write it again every step (vmap_sim_ahead(out=...)); 0: fresh allocation per step")
+                         "§6) and write it again every step (vmap_sim_ahead(out=...))")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
