@@ -342,7 +342,8 @@ def main():
         gather_ok = bool(torch.equal(gathered[rank * B:(rank + 1) * B], final_row(last_obs[0])))
     # HIP events on the launch stream (torch's current stream is the stream the C ABI is handed); with the gather enabled
     # the bracket also holds the (asynchronous) enqueue of the collective but no wait for it
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    per_step_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms = float(np.mean(per_step_ms)) if args.steps else float("nan")
     if args.path == "step":
         Kc = 1
         bytes_per_step = _native.step_bytes(env.ENV_ID, dtype)
@@ -403,7 +404,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "sim_ahead_kernel" if args.path == "sim_ahead" else "step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_step,
+                "kernel": "sim_ahead_kernel" if args.path == "sim_ahead" else "step_kernel", "kernel_ms": kernel_ms,
+                "kernel_ms_min_median_max": ([float(np.min(per_step_ms)), float(np.median(per_step_ms)), float(np.max(per_step_ms))]
+                                             if args.steps else None),  # spread over the timed steps (buffer placement)
+                "algorithmic_bytes_per_env_step": bytes_per_step,
                 "algorithmic_bytes_per_launch": algo_bytes, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
         }
