@@ -113,6 +113,9 @@ def build_env(args, device, rank):
     env.env_major_workspace = not getattr(args, "no_workspace", False)
     env.env_major_fused = not getattr(args, "no_fused", False)
     env.store_state_trajectory = not getattr(args, "obs_only", False)
+    if getattr(args, "no_pool", False):
+        env.trajectory_pool = False
+        env.trajectory_placement = "off"
     return env, state, actions, B, Kc, reg, solver, dtype
 
 
@@ -173,6 +176,58 @@ def cpu_baseline(args, reg, solver, dtype, tau, Kc):
     }
 
 
+def calibrate_placement(env, state, actions, args, Kc, B, dtype):
+    """Same-run calibration, outside the timed region: how fast does HBM take the trajectory launch's traffic WITHOUT arithmetic
+    over the very buffers a step writes (excenv_stream_pattern: same addresses, same order), how fast the same traffic with every
+    stream inside one buffer (one physical region at a time: the slow level of the platform), and a plain fill of
+    the same output buffers. Tells a slow box / placement from a slow kernel."""
+    from exciting_environments_amd import _native
+
+    if args.path != "sim_ahead" or args.traj_layout != "lane_major" or args.action_layout != "lane_major" or args.obs_only:
+        return None
+    isz = 4 if dtype == torch.float32 else 8
+    if (B * isz) % 16 or Kc < 8:
+        return None
+    obs, states, _last = env.vmap_sim_ahead(state, actions, env.tau, env.tau)  # the set the next step would write
+    leaves = [getattr(states.physical_state, n) for n in env.STATE_FIELDS]
+    A, O, S = env.action_dim, obs.shape[2], len(leaves)
+    rb = B * isz
+    stream = _native.raw_stream(torch.cuda.current_device())
+    rd, rd_rs = [actions.data_ptr() + c * rb for c in range(A)], [A * rb] * A
+    ob = obs.data_ptr()
+    obs_w, obs_rs = [ob + c * rb for c in range(O)], [O * rb] * O
+    rows = Kc - 1
+
+    def timed(fn, n=5):
+        fn()
+        ts = []
+        for _ in range(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts))
+
+    pat_bytes = (A + O + S) * rb * rows
+    t_pat = timed(lambda: _native.stream_pattern(rd, rd_rs, obs_w + [l.data_ptr() for l in leaves], obs_rs + [rb] * S, rb, rows, stream))
+    W = O + S  # every stream inside the observation buffer read as [rows'][O + S][B]: one region at any time, nothing written twice
+    rows1 = min(rows, (Kc + 1) * O // W)
+    t_one = timed(lambda: _native.stream_pattern(rd, rd_rs, [ob + q * rb for q in range(W)], [W * rb] * W, rb, rows1, stream)) * rows / rows1
+    flat = [obs.permute(1, 2, 0)] + [l.t() for l in leaves]  # the contiguous [rows, ., B] memory behind the views
+    assert all(t.is_contiguous() for t in flat)
+    fill_bytes = sum(t.numel() for t in flat) * isz
+
+    def fill():
+        for t in flat:
+            t.fill_(0.0)
+
+    t_fill = timed(fill)
+    return {"same_run_pattern_gbs": pat_bytes / t_pat / 1e6, "same_run_pattern_one_buffer_gbs": pat_bytes / t_one / 1e6,
+            "same_run_fill_gbs": fill_bytes / t_fill / 1e6, "same_run_pattern_ms": t_pat, "same_run_pattern_rows": rows}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +256,8 @@ def parse_args():
                          "§6) and write it again every step (vmap_sim_ahead(out=...))")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the same-run placement calibration after the timed region")
+    ap.add_argument("--no-pool", action="store_true", help="every step allocates its outputs (no pooled sets, no placement check)")
     return ap.parse_args()
 
 
@@ -322,11 +379,19 @@ def main():
         ev[k][0].record()
         state = one_step(state)
         ev[k][1].record()
+    gather_ms = None
     if gatherer is not None:
         if args.gather == "end" and last_obs[0] is not None:  # reassemble the global observation batch once
+            torch.cuda.synchronize()  # so that the collective's own time can be told from the stepping time
+            tg = time.perf_counter()
             gathered = gatherer.start(final_row(last_obs[0]), gathered)
-        gatherer.wait()
+            gatherer.wait()
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+        else:
+            gatherer.wait()
     torch.cuda.synchronize()
+    steps_elapsed = time.perf_counter() - t0  # this rank, before waiting for the others
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
@@ -344,6 +409,16 @@ def main():
     # the bracket also holds the (asynchronous) enqueue of the collective but no wait for it
     per_step_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_ms = float(np.mean(per_step_ms)) if args.steps else float("nan")
+    # every rank's own numbers (a slow rank decides the MAX-over-ranks time): kernel ms min / median / max, the rank's wall
+    # time for its steps (+ its share of the end gather), gathered to rank 0
+    mine = [float(np.min(per_step_ms)), float(np.median(per_step_ms)), float(np.max(per_step_ms)), steps_elapsed * 1e3,
+            -1.0 if gather_ms is None else gather_ms] if args.steps else [float("nan")] * 5
+    per_rank = [mine]
+    if world > 1:
+        t = torch.tensor(mine, dtype=torch.float64, device=device)
+        allr = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        per_rank = [[float(x) for x in r.cpu()] for r in allr]
     if args.path == "step":
         Kc = 1
         bytes_per_step = _native.step_bytes(env.ENV_ID, dtype)
@@ -366,6 +441,9 @@ def main():
         except Exception:
             traffic = None
 
+    calib = None
+    if rank == 0 and not args.no_calibration:
+        calib = calibrate_placement(env, state, actions, args, Kc, B, dtype)
     if rank == 0:
         total_steps = B * world * Kc * args.steps
         out = {
@@ -396,7 +474,10 @@ def main():
                 "collective": (gatherer.collective if gatherer is not None else None),
                 "gathered_slice_matches_local": gather_ok,
                 "outputs_finite": finite,
-                "output_buffers": ("fresh allocation per step" if bufs is None else
+                "output_buffers": (("library-pooled output sets: a set is written again once nothing refers to it (the plain "
+                                    "functional API, core_env.py trajectory sets); sets made this run: "
+                                    f"{len(getattr(env, '_traj_sets', []))}" if getattr(env, "trajectory_pool", False)
+                                    else "fresh allocation per step") if bufs is None else
                                    f"one set written again every step (vmap_sim_ahead(out=...)), chosen during set-up as the fastest "
                                    f"of {len(probe_ms) or 1} placements; probe launch ms per placement (rank 0): "
                                    + ", ".join(f"{t:.3f}" for t in probe_ms)),
@@ -407,10 +488,27 @@ def main():
                 "kernel": "sim_ahead_kernel" if args.path == "sim_ahead" else "step_kernel", "kernel_ms": kernel_ms,
                 "kernel_ms_min_median_max": ([float(np.min(per_step_ms)), float(np.median(per_step_ms)), float(np.max(per_step_ms))]
                                              if args.steps else None),  # spread over the timed steps (buffer placement)
+                "kernel_ms_spread_pct": (100.0 * (float(np.max(per_step_ms)) - float(np.min(per_step_ms))) / float(np.median(per_step_ms))
+                                         if args.steps else None),
+                "kernel_ms_per_step": [round(float(x), 4) for x in per_step_ms],
                 "algorithmic_bytes_per_env_step": bytes_per_step,
                 "algorithmic_bytes_per_launch": algo_bytes, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
         }
+        if calib is not None:  # same-run calibration of the placement (outside the timed region)
+            out["roofline"].update(calib)
+            out["roofline"]["kernel_vs_same_run_pattern"] = achieved / calib["same_run_pattern_gbs"]
+        out["roofline"]["placement_check"] = getattr(env, "last_placement", None)
+        # per-rank visibility: [kernel ms min, median, max, wall ms of this rank's timed steps, ms of the end all-gather or -1]
+        out["per_rank_kernel_ms"] = [[round(x, 4) for x in r[:3]] for r in per_rank]
+        out["per_rank_steps_wall_ms"] = [round(r[3], 3) for r in per_rank]
+        out["gather_ms"] = (None if all(r[4] < 0 for r in per_rank) else max(r[4] for r in per_rank))
+        med_rank = float(np.median([r[1] for r in per_rank]))
+        slow_rank = float(np.max([r[1] for r in per_rank]))
+        # whole-job rate if every rank ran its launches at the median rank's / the slowest rank's median kernel time (no gather):
+        # the ingredients of a weak-scaling comparison; the efficiency itself is the driver's to compute from per-N values
+        out["value_at_median_rank_kernel"] = B * world * Kc / (med_rank * 1e-3) if args.steps else None
+        out["value_at_slowest_rank_kernel"] = B * world * Kc / (slow_rank * 1e-3) if args.steps else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, reg, solver, dtype, env.tau, Kc)
         print(json.dumps(out), flush=True)

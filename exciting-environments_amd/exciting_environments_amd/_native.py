@@ -17,7 +17,7 @@ LAYOUT_ENV_MAJOR, LAYOUT_LANE_MAJOR, LAYOUT_TILED = 0, 1, 2
 TILE = 1024  # EXCENV_TILE
 SEM_STEP, SEM_AHEAD = 0, 1
 F32, F64 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _LIB_PATH = os.environ.get(  # EXCENV_HIP_LIB: A/B-test another build of the same library (tuning experiments)
     "EXCENV_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libexcenv_hip.so"))
@@ -91,7 +91,7 @@ def lib():
         l.excenv_truncated_width.restype = ctypes.c_int32
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
                    "excenv_probe_math", "excenv_probe_div", "excenv_rew_trunc_term", "excenv_state_from_observation",
-                   "excenv_update_ref", "excenv_update_ref_to", "excenv_random_state", "excenv_observe"):
+                   "excenv_update_ref", "excenv_update_ref_to", "excenv_random_state", "excenv_observe", "excenv_stream_pattern"):
             getattr(l, fn).restype = ctypes.c_int
         vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
         # typed prototypes: plain Python ints / floats / None / byref() pass without per-call ctypes wrapping
@@ -99,6 +99,7 @@ def lib():
         l.excenv_gym_step.argtypes = [ci, ci, ci, cl, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         l.excenv_sim_ahead_ws.argtypes = [ci, ci, ci, cl, cl, ctypes.c_int32, vp, vp, cd, cd, vp, vp, ci, vp, vp, ci, vp, ci, vp,
                                           vp, cl, vp, vp]
+        l.excenv_stream_pattern.argtypes = [ctypes.c_int32, vp, vp, ctypes.c_int32, vp, vp, cl, cl, ctypes.c_int32, vp]
         if l.excenv_abi_version() != ABI_VERSION:
             raise ImportError("libexcenv_hip.so: ABI version mismatch")
         _lib = l
@@ -180,6 +181,19 @@ def step_raw(env_id, solver_id, dtype_code, B, props_ref, control_ref, tau, in_p
                                   obs_ptr, gym[0], gym[1], gym[2], opts_ref, stream)
     if rc != 0:
         _check(rc, "excenv_step" if gym is None else "excenv_gym_step")
+
+
+def stream_pattern(read_ptrs, read_row_strides, write_ptrs, write_row_strides, row_bytes: int, rows: int, stream: int,
+                   nontemporal: bool = True):
+    """excenv_stream_pattern: the trajectory kernels' access shape without arithmetic over raw device addresses (calibration;
+    whatever the write streams point at is overwritten with meaningless values)."""
+    nr, nw = len(read_ptrs), len(write_ptrs)
+    rc = lib().excenv_stream_pattern(
+        nr, (ctypes.c_void_p * max(nr, 1))(*read_ptrs), (ctypes.c_int64 * max(nr, 1))(*read_row_strides),
+        nw, (ctypes.c_void_p * max(nw, 1))(*write_ptrs), (ctypes.c_int64 * max(nw, 1))(*write_row_strides),
+        int(row_bytes), int(rows), int(bool(nontemporal)), stream)
+    if rc != 0:
+        _check(rc, "excenv_stream_pattern")
 
 
 def env_dims(env_id: int):

@@ -118,6 +118,14 @@ class CoreEnvironment(ABC):
         # vmap_step fast path (see _vmap_step_launch): output slots carved from one allocation per `n` calls, pointer arrays
         # pre-built per slot, and the identity of the state we returned last (its pointer array is the next call's input)
         self._slots = {False: None, True: None}
+        # large vmap_sim_ahead outputs (see _TrajSet): dead output sets are written again instead of re-allocated, and a new
+        # set is checked for a slow physical placement before its first use. Both are invisible to callers (the functional
+        # contract holds: a set is handed out again only when nothing can observe it); knobs for experiments:
+        self.trajectory_pool = True          # False: every large call allocates its outputs (the behaviour up to round 2)
+        self.trajectory_placement = "auto"   # "off": take the first placement the allocator gives
+        self.last_placement = None           # diagnostics of the most recent placement check (dict) or None
+        self._traj_sets = []
+        self._placement_best = {}
         self._traj_bcast_cache = None
         self._ws_bytes_cache = None
         self._last_out = None
@@ -594,7 +602,13 @@ class CoreEnvironment(ABC):
                 tens = [self._t(r, (B,)) for r in refs]
                 otens = None if obs_refs is None else [self._t(r, (B,)) for r in obs_refs]  # gym_step: obs shows these
                 ctl = _native.make_control([self.STATE_FIELDS.index(n) for n in self.control_state], tens, otens)
-                cc = self._ctl_cache = (key, (refs, obs_refs), (tens, otens), ctl, ctypes.byref(ctl))
+                cc = (key, (refs, obs_refs), (tens, otens), ctl, ctypes.byref(ctl))
+                # The struct holds the pointers of `tens`. Keep it across calls only when those ARE the caller's leaves:
+                # a converted copy (CPU / other dtype / non-contiguous leaf) would go stale when the caller updates the
+                # original in place (same id), so such leaves are converted again on every call.
+                same = all(t is r for t, r in zip(tens, refs)) and (
+                    otens is None or all(t is r for t, r in zip(otens, obs_refs)))
+                self._ctl_cache = cc if same else None
             control_ref = cc[4]
         props, _keep = self._props_for(self.env_properties, B)
         idx = dev.index
@@ -906,6 +920,146 @@ class CoreEnvironment(ABC):
             return observations, st_views, last, N, gym_out
         return observations, st_views, last, N
 
+    # -- large trajectory outputs ----------------------------------------------------------------------------------------
+    # Where the driver places tens of GB of trajectory buffers in physical memory moves the trajectory kernel by 15-19 %
+    # (tools/microbench/placement_pattern.hip): device memory consists of large physical regions, and write traffic
+    # that falls into ONE region at a time — observations and state leaves allocated back to back by a fresh process — runs
+    # at ~5.0 TB/s where the same kernel over buffers in two regions runs at ~5.9 TB/s; a plain sequential fill shows the same
+    # two levels, so this is the platform, not the kernel. Virtual addresses say nothing about the region, so a new set of
+    # output buffers is CHECKED: the library's no-arithmetic access pattern (excenv_stream_pattern) is timed once with every
+    # stream inside the observation buffer (one region at any time: the slow level, by construction) and once over the
+    # candidate (observations + a state-leaf block); a candidate that is not clearly faster is kept allocated as a spacer while
+    # another block is tried (at most _PLACEMENT_TRIES, then the best one seen is taken). Cost: a few launches of the size of one
+    # trajectory call, once per set. Sets are then pooled: a dead set (same test as the vmap_step slots: no Python reference,
+    # no C++ holder, no foreign view, same stream) is written again instead of allocating a new one, so a chained run
+    # (`obs, states, last = env.vmap_sim_ahead(last, actions, ...)`) alternates between two checked sets.
+    class _TrajSet:
+        __slots__ = ("key", "obs_buf", "st_buf", "lbuf", "observations", "st_views", "last", "obs_ptr", "traj_ptrs", "last_ptrs",
+                     "tens", "storages", "rc0", "use0", "stream", "placement")
+
+    _PLACED_TRAJ_BYTES = 1 << 30  # output sets at least this large go through the placement check
+    _PLACEMENT_TRIES = 4
+    _PLACEMENT_ACCEPT = 0.93      # candidate time / one-region time at or below this: the set spans regions
+    _TRAJ_POOL_SETS = 2
+
+    def release_trajectory_buffers(self):
+        """Drop the pooled (dead) trajectory output sets so that their memory returns to torch's allocator."""
+        self._traj_sets = []
+
+    def _time_pattern(self, read_ptrs, read_rs, write_ptrs, write_rs, row_bytes, rows, stream):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        _native.stream_pattern(read_ptrs, read_rs, write_ptrs, write_rs, row_bytes, rows, stream)  # warm
+        ev[0].record()
+        _native.stream_pattern(read_ptrs, read_rs, write_ptrs, write_rs, row_bytes, rows, stream)
+        ev[1].record()
+        ev[1].synchronize()
+        return float(ev[0].elapsed_time(ev[1]))
+
+    def _place_state_block(self, obs_buf, B, rows, OW, S, isz, actions):
+        """A [S, rows, B] block for the state leaves of a new set whose traffic, together with the observations', does not fall
+        into one physical region (see above). Returns (block, diagnostics)."""
+        dt, dev = self.dtype, self.device
+        block = torch.empty((S, rows, B), dtype=dt, device=dev)
+        nbytes = (OW + S) * rows * B * isz
+        if (self.trajectory_placement != "auto" or nbytes < self._PLACED_TRAJ_BYTES or (B * isz) % 16 or rows < 8 or S > OW
+                or torch.cuda.is_current_stream_capturing()):
+            return block, None
+        stream = _native._raw_stream(dev)
+        rb, prow = B * isz, rows - 2
+        ob = obs_buf.data_ptr()
+        rd, rd_rs = [], []
+        if actions is not None:  # lane-major [K, A, B] actions: the read streams of the launch
+            A = self.action_dim
+            rd = [actions.data_ptr() + c * rb for c in range(A)]
+            rd_rs = [A * rb] * A
+            prow = min(prow, actions.shape[1])
+        obs_w, obs_rs = [ob + c * rb for c in range(OW)], [OW * rb] * OW
+        W = OW + S
+        with _native._on_device(dev):
+            # Reference level: every stream inside ONE buffer read as [rows'][OW + S][B] (no address written twice) — at any time
+            # the launch's traffic then lies within a few hundred MB, i.e. in one region wherever that buffer is contiguous in
+            # physical memory. It is only a reference, not a guarantee (a buffer backed by scattered pages is "fast" even so):
+            # a candidate is accepted when it is clearly faster than the SLOWEST time seen so far, references included.
+            prow1 = min(prow, rows * OW // W)
+            t_ref = self._time_pattern(rd, rd_rs, [ob + q * rb for q in range(W)], [W * rb] * W, rb, prow1, stream) * prow / prow1
+            slowest, tried = t_ref, []
+            pkey = (B, rows, OW, S, len(rd))
+            known = self._placement_best.get(pkey)
+            if known is not None:
+                slowest = max(slowest, known / self._PLACEMENT_ACCEPT * 0.999)  # what was fast before is the bar now
+            for _ in range(self._PLACEMENT_TRIES):
+                base = block.data_ptr()
+                t = self._time_pattern(rd, rd_rs, obs_w + [base + j * rows * rb for j in range(S)], obs_rs + [rb] * S, rb, prow,
+                                       stream)
+                tried.append((t, block))
+                slowest = max(slowest, t)
+                # a later set of the same shape should also match the best placement an earlier set of this environment found
+                good = min(x for x, _ in tried) <= self._PLACEMENT_ACCEPT * slowest and (known is None or t <= 1.03 * known)
+                if good or len(tried) == self._PLACEMENT_TRIES:
+                    break
+                try:  # the rejected block stays allocated while the next one is made, so that it lands somewhere else
+                    block = torch.empty((S, rows, B), dtype=dt, device=dev)
+                except torch.OutOfMemoryError:
+                    break
+        t_best, best = min(tried, key=lambda tb: tb[0])
+        self._placement_best[pkey] = t_best if known is None else min(known, t_best)
+        gbs = lambda t: (len(rd) + OW + S) * rb * prow / t / 1e6
+        diag = {"one_buffer_reference_ms": t_ref, "candidate_ms": [t for t, _ in tried],
+                "chosen": [t for t, _ in tried].index(t_best), "clearly_faster_than_slowest_seen": bool(t_best <= self._PLACEMENT_ACCEPT * slowest),
+                "rows": prow, "slowest_seen_gbs": gbs(slowest), "chosen_gbs": gbs(t_best)}
+        del tried, block
+        return best, diag
+
+    def _traj_set_is_free(self, ts, stream) -> bool:
+        if ts.rc0 is None or ts.stream != stream:
+            return False
+        if tuple(map(sys.getrefcount, ts.tens)) != ts.rc0:
+            return False
+        if sum(map(CoreEnvironment._tensor_use_count, ts.tens)) != len(ts.tens):
+            return False
+        return [CoreEnvironment._storage_use_count(st._cdata) for st in ts.storages] == ts.use0
+
+    def _traj_set_for(self, B, rows, OW, S, want_states, last_e, isz, actions):
+        dt, dev = self.dtype, self.device
+        key = (B, rows, OW, S, want_states, dt)
+        capturing = torch.cuda.is_current_stream_capturing()
+        pooled = (self.trajectory_pool and not capturing and CoreEnvironment._storage_use_count is not None
+                  and CoreEnvironment._tensor_use_count is not None)
+        stream = _native._raw_stream(dev)
+        if pooled:
+            for k, ts in enumerate(self._traj_sets):
+                if ts.key == key and self._traj_set_is_free(ts, stream):
+                    self._traj_sets.append(self._traj_sets.pop(k))  # most recently used last
+                    return ts
+            self._traj_sets = [t for t in self._traj_sets if t.key == key][-(self._TRAJ_POOL_SETS - 1):] if self._TRAJ_POOL_SETS > 1 else []
+        ts = CoreEnvironment._TrajSet()
+        ts.key = key
+        ts.obs_buf = torch.empty((rows, OW, B), dtype=dt, device=dev)
+        ts.placement = None
+        if want_states:
+            ts.st_buf, ts.placement = self._place_state_block(ts.obs_buf, B, rows, OW, S, isz, actions)
+            self.last_placement = ts.placement
+            sb = ts.st_buf.data_ptr()
+            ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (rows * B, 1, B)).unbind(0))
+            ts.traj_ptrs = _native.ptr_array([sb + j * rows * B * isz for j in range(S)])
+        else:
+            ts.st_buf, ts.st_views, ts.traj_ptrs = None, None, None
+        ts.lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
+        ts.observations = ts.obs_buf.permute(2, 0, 1)
+        ts.last = tuple(ts.lbuf[:, :B].unbind(0))
+        ts.obs_ptr = ts.obs_buf.data_ptr()
+        lb = ts.lbuf.data_ptr()
+        ts.last_ptrs = _native.ptr_array([lb + j * last_e * isz for j in range(S)])
+        ts.tens = (ts.observations,) + (ts.st_views or ()) + ts.last
+        ts.storages = [t.untyped_storage() for t in ((ts.obs_buf, ts.lbuf) + ((ts.st_buf,) if want_states else ()))]
+        ts.rc0 = ts.use0 = ts.stream = None
+        if pooled:
+            ts.stream = stream
+            ts.rc0 = tuple(map(sys.getrefcount, ts.tens))
+            ts.use0 = [CoreEnvironment._storage_use_count(st._cdata) for st in ts.storages]
+            self._traj_sets.append(ts)
+        return ts
+
     # Trajectories up to this size come out of ONE allocation (observations, state leaves and last_state are views of it):
     # at RL / MPC batch sizes the launch takes ~100 us and 2 S + 1 allocator calls plus as many view objects cost as much.
     # Larger outputs keep one allocation per returned array so that dropping the states frees their memory.
@@ -976,17 +1130,10 @@ class CoreEnvironment(ABC):
             last_ptrs = _native.ptr_array([base + (traj_e + j * last_e) * isz for j in range(S)])
             obs_ptr = base
         else:
-            obs_buf = torch.empty((rows, OW, B), dtype=dt, device=dev)
-            observations = obs_buf.permute(2, 0, 1)
-            obs_ptr = obs_buf.data_ptr()
-            if want_states:
-                st_buf = [torch.empty((rows, B), dtype=dt, device=dev) for _ in range(S)]
-                st_views = [b.t() for b in st_buf]
-                traj_ptrs = _native._ptrs(st_buf)
-            lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
-            last = lbuf[:, :B].unbind(0)
-            lb = lbuf.data_ptr()
-            last_ptrs = _native.ptr_array([lb + j * last_e * isz for j in range(S)])
+            ts = self._traj_set_for(B, rows, OW, S, want_states, last_e, isz,
+                                    actions if (a_layout == _native.LAYOUT_LANE_MAJOR and sub == 1 and K > 0) else None)
+            observations, st_views, last = ts.observations, ts.st_views, ts.last
+            obs_ptr, traj_ptrs, last_ptrs = ts.obs_ptr, ts.traj_ptrs, ts.last_ptrs
             if ws_e:
                 ws = torch.empty(ws_e, dtype=dt, device=dev)  # stream-ordered: free to die when this function returns
                 ws_ptr = ws.data_ptr()
@@ -1012,14 +1159,19 @@ class CoreEnvironment(ABC):
         if ck is not None and ck[0] == shape and len(ck[1]) == len(src) and all(a is b for a, b in zip(ck[1], src)):
             ref, key = ck[2], ck[3]
         else:
-            ref = self.PhysicalState(*[
-                self._t(r).reshape(lead_shape + (1,)).expand(shape) for r in src[:-1]
-            ])
+            conv = [self._t(r) for r in src[:-1]]
+            ref = self.PhysicalState(*[t.reshape(lead_shape + (1,)).expand(shape) for t in conv])
             if _random.is_key(init_state.PRNGKey):
                 key = init_state.PRNGKey.reshape(lead_shape + (1, 2)).expand(shape + (2,))
+                key_same = True
             else:
-                key = self._t(init_state.PRNGKey).reshape(lead_shape + (1,)).expand(shape)
-            self._traj_bcast_cache = (shape, src, ref, key)
+                kt = self._t(init_state.PRNGKey)
+                key = kt.reshape(lead_shape + (1,)).expand(shape)
+                key_same = kt is init_state.PRNGKey
+            # views of the caller's own leaves follow in-place updates of those leaves; converted COPIES (CPU / other dtype /
+            # non-contiguous leaf) would go stale under the same id, so those are rebuilt on every call
+            same = key_same and all(t is r for t, r in zip(conv, src[:-1]))
+            self._traj_bcast_cache = (shape, src, ref, key) if same else None
         return self.State(physical_state=phys, PRNGKey=key, additions=self._additions(shape, True), reference=ref)
 
     def sim_ahead(self, init_state, actions, env_properties, obs_stepsize, action_stepsize):

@@ -32,8 +32,9 @@
 extern "C" {
 #endif
 
-/* 4: v3 + excenv_random_state, excenv_update_ref_to, excenv_observe (additions only; every v3 signature is unchanged) */
-#define EXCENV_ABI_VERSION 4
+/* 4: v3 + excenv_random_state, excenv_update_ref_to, excenv_observe (additions only; every v3 signature is unchanged)
+ * 5: v4 + excenv_stream_pattern (addition only) */
+#define EXCENV_ABI_VERSION 5
 
 /* Environment ids. Field orders follow the reference dataclasses. */
 typedef enum {
@@ -271,6 +272,20 @@ int excenv_update_ref_to(int env, int dtype, int64_t B, const excenv_props_t* pr
  * leaves, key_leaf [B][2] the keys that become State.PRNGKey. Same samplers as excenv_update_ref. */
 int excenv_random_state(int env, int dtype, int64_t B, const excenv_props_t* props, const int64_t* keys,
                         void* const* state_out, int64_t* key_leaf, void* stream);
+
+/* ---- calibration, no reference counterpart: the memory access shape of excenv_sim_ahead (lane-major buffers) without any
+ * arithmetic. `rows` times, every workgroup reads one 4 KiB piece of each of n_read streams and writes one 4 KiB piece of each
+ * of n_write streams (16 bytes per lane, 256 lanes); stream s covers bytes [0, row_bytes) of its row and advances by its own
+ * row stride: for a trajectory call the read streams are the A action components (base actions + c*B*w, row stride A*B*w), the
+ * write streams the O observation components (base obs + c*B*w, row stride O*B*w) and the S state leaves (row stride B*w), with
+ * row_bytes = B*w and rows = K*substeps. What is written is meaningless: use it on buffers whose contents are dead. It tells,
+ * in the same process and over the very buffers of a trajectory call, how fast HBM takes that traffic where the driver placed
+ * those buffers (bench.py: roofline.same_run_pattern_gbs; the Python mirror uses it to reject slow placements of large
+ * trajectory buffers before the first trajectory is written). n_read <= 4, n_write <= 32; bases and strides
+ * 16-byte aligned; nontemporal != 0 selects the streaming stores the trajectory kernels use. */
+int excenv_stream_pattern(int32_t n_read, const void* const* read_base, const int64_t* read_row_stride_bytes,
+                          int32_t n_write, void* const* write_base, const int64_t* write_row_stride_bytes,
+                          int64_t row_bytes, int64_t rows, int32_t nontemporal, void* stream);
 
 /* ---- device-math probes (tests only): out[i] = f(in[i]) for the in-kernel fp32 routines -- */
 int excenv_probe_math(int which /*0 sin,1 cos,2 wrap_angle*/, int dtype, int64_t n,

@@ -381,3 +381,34 @@ def test_generate_observation_kernel_equals_the_torch_twin(reg, dtype):
     obs_r, st_r = env.vmap_reset()
     obs_c, _ = cpu.vmap_reset()
     assert torch.allclose(obs_r.cpu(), obs_c, rtol=0, atol=3e-7, equal_nan=True)
+
+
+@pytest.mark.parametrize("kind", ["float64_leaf", "cpu_leaf"])
+def test_reference_leaf_that_needs_conversion_is_reread_after_in_place_update(kind):
+    """A reference leaf that is not already a device tensor of the env dtype is converted to a copy for the launch. The copy
+    must not be kept under the identity of the original: an in-place update of the original between two calls keeps its id."""
+    B = 512
+    env, props, spec, st, refs, act = _problem("mass_spring_damper", B, torch.float32, ["velocity"], seed=77)
+    state = to_state(env, st, reference=refs)
+    if kind == "float64_leaf":
+        leaf = torch.as_tensor(refs["velocity"], dtype=torch.float64, device=env.device)
+    else:
+        leaf = torch.as_tensor(refs["velocity"], dtype=torch.float32, device="cpu")
+    state.reference.velocity = leaf
+    a = torch.as_tensor(act, device=env.device)
+    obs1, rew1, _, _, _ = env.vmap_gym_step(state, a)
+    obs1, rew1 = obs1.clone(), rew1.clone()
+    leaf.mul_(0.25)  # same object, same id, new values
+    obs2, rew2, _, _, _ = env.vmap_gym_step(state, a)
+    fresh = to_state(env, st, reference={"velocity": leaf.cpu().numpy().astype(np.float32)})
+    obs3, rew3, _, _, _ = env.vmap_gym_step(fresh, a)
+    assert torch.equal(obs2, obs3) and torch.equal(rew2, rew3)
+    assert not torch.equal(rew1, rew2) and not torch.equal(obs1[:, -1], obs2[:, -1])
+    # the trajectory path's broadcast reference views: same rule
+    acts = torch.zeros((B, 3, env.action_dim), device=env.device)
+    _, states1, _ = env.vmap_sim_ahead(state, acts, env.tau, env.tau)
+    r1 = states1.reference.velocity.clone()
+    leaf.mul_(2.0)
+    _, states2, _ = env.vmap_sim_ahead(state, acts, env.tau, env.tau)
+    assert torch.equal(states2.reference.velocity[:, 0].cpu(), leaf.to(torch.float32).cpu())
+    assert not torch.equal(r1, states2.reference.velocity)

@@ -1,0 +1,162 @@
+"""Large vmap_sim_ahead outputs: pooled output sets (a dead set is written again, never a live one), the placement check
+that runs once per new set, and the calibration entry point excenv_stream_pattern behind it. The functional contract of the
+reference (core_env.py:571-616: every call returns arrays nothing else refers to, inputs are never written) must hold with
+the pool on. ``-m gpu``."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from exciting_environments_amd import _native
+from helpers import NP_DTYPE, make_env, random_state, spec_of, to_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(env_name="pmsm", B=4096, dtype=torch.float32, pool=True, placed=True):
+    env, props, keep, spec = make_env(env_name, B, dtype)
+    env._SHARED_TRAJ_BYTES = 0  # test sizes through the path of the large outputs
+    env._PLACED_TRAJ_BYTES = 0 if placed else (1 << 62)
+    env.trajectory_pool = pool
+    st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=5)
+    return env, to_state(env, st)
+
+
+def _actions(env, K, seed):
+    a = env.new_actions_buffer(K)
+    g = torch.Generator(device=env.device)
+    g.manual_seed(seed)
+    a.copy_((torch.rand((K, env.action_dim, env.batch_size), generator=g, device=env.device, dtype=env.dtype) * 2 - 1).permute(2, 0, 1))
+    return a
+
+
+def _leaves(env, st):
+    return [getattr(st.physical_state, n) for n in env.STATE_FIELDS]
+
+
+@pytest.mark.parametrize("env_name", ["pmsm", "pendulum"])
+def test_chained_run_alternates_between_two_sets_and_equals_the_unpooled_run(env_name):
+    K = 16
+    env, s0 = _env(env_name)
+    ref_env, r0 = _env(env_name, pool=False, placed=False)
+    acts = [_actions(env, K, 100 + i) for i in range(6)]
+    ptrs, state, rstate = [], s0, r0
+    for a in acts:
+        obs, states, state = env.vmap_sim_ahead(state, a, env.tau, env.tau)
+        robs, rstates, rstate = ref_env.vmap_sim_ahead(rstate, a, env.tau, env.tau)
+        assert torch.equal(obs, robs)
+        for x, y in zip(_leaves(env, states), _leaves(ref_env, rstates)):
+            assert torch.equal(x, y)
+        for x, y in zip(_leaves(env, state), _leaves(ref_env, rstate)):
+            assert torch.equal(x, y)
+        ptrs.append(obs.data_ptr())
+        del obs, states
+    assert len(set(ptrs)) == 2 and ptrs[0] == ptrs[2] == ptrs[4] and ptrs[1] == ptrs[3] == ptrs[5]
+    assert len(env._traj_sets) == 2
+    assert env.last_placement is not None and len(env.last_placement["candidate_ms"]) >= 1
+
+
+@pytest.mark.parametrize("held", ["observations", "state_leaf", "last_leaf", "view", "states_object", "detach"])
+def test_a_set_somebody_can_still_see_is_never_written_again(held):
+    K = 12
+    env, s0 = _env("pmsm", B=2048)
+    a = _actions(env, K, 7)
+    obs, states, last = env.vmap_sim_ahead(s0, a, env.tau, env.tau)
+    keep_obs, keep_leaf, keep_last = obs.clone(), states.physical_state.i_q.clone(), last.physical_state.i_q.clone()
+    if held == "observations":
+        holder = obs
+    elif held == "state_leaf":
+        holder = states.physical_state.i_q
+    elif held == "last_leaf":
+        holder = last.physical_state.i_q
+    elif held == "view":
+        holder = obs[:, -1, :]
+    elif held == "states_object":
+        holder = states
+    else:
+        holder = obs.detach()
+    first_ptr = obs.data_ptr()
+    del obs, states, last
+    for i in range(4):  # other inputs: a reused set would show different values
+        o2, s2, l2 = env.vmap_sim_ahead(s0, _actions(env, K, 50 + i), env.tau, env.tau)
+        assert o2.data_ptr() != first_ptr
+        del o2, s2, l2
+    if held in ("observations", "detach"):
+        assert torch.equal(holder, keep_obs)
+    elif held == "state_leaf":
+        assert torch.equal(holder, keep_leaf)
+    elif held == "last_leaf":
+        assert torch.equal(holder, keep_last)
+    elif held == "view":
+        assert torch.equal(holder, keep_obs[:, -1, :])
+    else:
+        assert torch.equal(holder.physical_state.i_q, keep_leaf)
+    del holder
+    o3, s3, l3 = env.vmap_sim_ahead(s0, a, env.tau, env.tau)  # nothing refers to the first set any more: it comes back
+    assert o3.data_ptr() == first_ptr
+    assert torch.equal(o3, keep_obs)
+
+
+def test_a_set_is_not_reused_from_another_stream_and_inputs_are_never_written():
+    K = 10
+    env, s0 = _env("pendulum", B=1024)
+    a = _actions(env, K, 3)
+    before = [t.clone() for t in _leaves(env, s0)]
+    obs, states, last = env.vmap_sim_ahead(s0, a, env.tau, env.tau)
+    p0 = obs.data_ptr()
+    del obs, states, last
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        o2, _, _ = env.vmap_sim_ahead(s0, a, env.tau, env.tau)
+        assert o2.data_ptr() != p0
+    side.synchronize()
+    for x, y in zip(_leaves(env, s0), before):
+        assert torch.equal(x, y)
+    env.release_trajectory_buffers()
+    assert env._traj_sets == []
+
+
+def test_last_state_of_a_pooled_set_feeds_the_next_call_without_aliasing():
+    """`state = last` keeps the previous set's last_state alive as the input of the next call: that set must stay busy."""
+    K = 9
+    env, s0 = _env("mass_spring_damper", B=1024)
+    ref_env, r0 = _env("mass_spring_damper", B=1024, pool=False, placed=False)
+    state, rstate = s0, r0
+    for i in range(5):
+        a = _actions(env, K, 20 + i)
+        _, _, state = env.vmap_sim_ahead(state, a, env.tau, env.tau)
+        _, _, rstate = ref_env.vmap_sim_ahead(rstate, a, env.tau, env.tau)
+    for x, y in zip(_leaves(env, state), _leaves(ref_env, rstate)):
+        assert torch.equal(x, y)
+
+
+def test_stream_pattern_touches_exactly_the_rows_it_is_given():
+    dev = torch.device("cuda")
+    row_elems, rows_total, rows = 4096 + 8, 12, 7  # a ragged last 4 KiB piece
+    rb = row_elems * 4
+    rd = torch.ones((rows_total, 2, row_elems), device=dev)
+    wr = torch.full((3, rows_total, row_elems), -5.0, device=dev)
+    stream = _native.raw_stream(torch.cuda.current_device())
+    _native.stream_pattern([rd.data_ptr(), rd.data_ptr() + rb], [2 * rb, 2 * rb], [wr[q].data_ptr() for q in range(3)], [rb] * 3, rb,
+                           rows, stream)
+    torch.cuda.synchronize()
+    w = wr.cpu().numpy()
+    assert np.all(w[:, rows:, :] == -5.0)
+    for q in range(3):  # row n holds the running sum of the two read streams (2 per row) + the stream index
+        for n in range(rows):
+            assert np.all(w[q, n] == 2.0 * (n + 1) + q)
+
+
+def test_stream_pattern_rejects_bad_arguments():
+    lib = _native.lib()
+    buf = torch.zeros(1024, device="cuda")
+    p = (ctypes.c_void_p * 1)(buf.data_ptr())
+    rs = (ctypes.c_int64 * 1)(4096)
+    assert lib.excenv_stream_pattern(0, None, None, 1, p, rs, 4096, 1, 1, None) == 0
+    assert lib.excenv_stream_pattern(0, None, None, 1, p, rs, 4090, 1, 1, None) == -1  # row_bytes not a multiple of 16
+    assert lib.excenv_stream_pattern(0, None, None, 33, p, rs, 4096, 1, 1, None) == -1
+    assert lib.excenv_stream_pattern(0, None, None, 1, None, rs, 4096, 1, 1, None) == -2
+    p_odd = (ctypes.c_void_p * 1)(buf.data_ptr() + 4)
+    assert lib.excenv_stream_pattern(0, None, None, 1, p_odd, rs, 4096, 1, 1, None) == -1
+    torch.cuda.synchronize()
