@@ -65,6 +65,7 @@ template <typename T, class M> struct SimArgs {
   int32_t control_idx[EXCENV_MAX_CONTROL];
   const T* reference[EXCENV_MAX_CONTROL];
   T dt, env_tau, adv_coef;
+  T lin_stop;  // tau * (K - 1) folded in double (PMSM predicted angles, Ctx::lin_stop)
   // optional gym trajectories (all three or none; GENERAL instantiation): reward / terminated hold rows 1..N at step
   // index n-1 with element strides (g_sb, g_sk); truncated holds rows 0..N with strides (t_sb, t_sk, t_sc)
   T* reward;
@@ -355,6 +356,9 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   const int64_t i0 = blk0 + lane_env;
   Ctx<T, M> c;
   load_ctx<GENERAL>(c, ka.kp, (i0 < ka.B) ? i0 : 0, ka.dt, ka.env_tau, ka.adv_coef);
+  c.lin_stop = ka.lin_stop;
+  c.lin_div = T(ka.K - 1);
+  c.lin_last = ka.K - 1;
   stage_lut<M, T>(c, ka.kp);
   if constexpr (M::HAS_LUT) c.lut_lds = LUT_LDS ? 1 : 0;  // == ka.kp.lut_lds (launch_sim_v picks the instantiation by it)
   if (i0 >= ka.B) return;  // host guarantees B % V == 0

@@ -50,6 +50,9 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
   const int nenv = (int)((ka.B - b0 < EM_LANES) ? (ka.B - b0) : EM_LANES);  // envs of this workgroup
   Ctx<T, M> c;
   load_ctx<BATCHED>(c, ka.kp, active ? i0 : 0, ka.dt, ka.env_tau, ka.adv_coef);
+  c.lin_stop = ka.lin_stop;
+  c.lin_div = T(ka.K - 1);
+  c.lin_last = ka.K - 1;
 
   T st[S];
 #pragma unroll

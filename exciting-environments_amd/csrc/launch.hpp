@@ -209,9 +209,12 @@ static inline int check_launch(const char* what) {
   return EXCENV_OK;
 }
 
-// PMSM: deadtime must be a broadcast scalar in {0, 1} (only one buffered action is representable in the
-// reference's state, pmsm_env.py:866-875); returns the double-folded (deadtime + 0.5) * tau.
-template <class M> static int pmsm_coef(const excenv_props_t* p, double env_tau, double* coef) {
+// PMSM dead time: a broadcast non-negative integer. The reference's state holds ONE buffered action, so any deadtime > 0 is a
+// one-step delay (PMSM.step, pmsm_env.py:866-875) while the clip's angle advance uses the full (deadtime + 0.5) * tau
+// (pmsm_env.py:599-604) — returned here, folded in double like the Python expression. `ahead`: the reference's sim_ahead
+// override assembles deadtime + K buffer rows for K + 1 saved rows (pmsm_env.py:765-791), which only works for deadtime 0 / 1
+// (its own vmap rejects the shapes otherwise), so EXCENV_SEM_AHEAD takes 0 / 1 only; EXCENV_SEM_STEP (K exact steps) takes any.
+template <class M> static int pmsm_coef(const excenv_props_t* p, double env_tau, double* coef, bool ahead = false) {
   *coef = 0.0;
   if constexpr (M::IS_PMSM) {
     const excenv_param_t& d = p->static_params[6];
@@ -219,8 +222,13 @@ template <class M> static int pmsm_coef(const excenv_props_t* p, double env_tau,
       set_error("PMSM: static_params.deadtime must be a scalar, not a per-env array");
       return EXCENV_EUNSUPPORTED;
     }
-    if (!(d.value == 0.0 || d.value == 1.0)) {
-      set_error("PMSM: deadtime must be 0 or 1 (got %g)", d.value);
+    if (!(d.value >= 0.0) || d.value != (double)(int64_t)d.value || d.value > 1e6) {
+      set_error("PMSM: deadtime must be a non-negative integer (got %g)", d.value);
+      return EXCENV_EUNSUPPORTED;
+    }
+    if (ahead && d.value > 1.0) {
+      set_error("PMSM: EXCENV_SEM_AHEAD supports deadtime 0 or 1 (got %g): the reference's sim_ahead builds K + deadtime buffer "
+                "rows for K + 1 saved rows (pmsm_env.py:765-791) and fails for more; use EXCENV_SEM_STEP", d.value);
       return EXCENV_EUNSUPPORTED;
     }
     *coef = (d.value + 0.5) * env_tau;
@@ -337,7 +345,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   std::memset(&ka, 0, sizeof(ka));
   const bool batched = fill_props<T, M>(ka.kp, sc.props);
   double coef;
-  if (int rc = pmsm_coef<M>(sc.props, sc.env_tau, &coef)) return rc;
+  if (int rc = pmsm_coef<M>(sc.props, sc.env_tau, &coef, sc.semantics == EXCENV_SEM_AHEAD)) return rc;
   if (M::IS_PMSM && sc.substeps != 1) {
     set_error("PMSM: obs_stepsize must equal action_stepsize (reference pmsm_env.py:787)");
     return EXCENV_EUNSUPPORTED;
@@ -413,6 +421,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   ka.dt = (T)sc.obs_stepsize;
   ka.env_tau = (T)sc.env_tau;
   ka.adv_coef = (T)coef;
+  ka.lin_stop = (T)(sc.env_tau * (double)(sc.K > 0 ? sc.K - 1 : 0));
   if (sc.B == 0) return EXCENV_OK;
   {  // per-lane offsets are 32-bit: 256 lanes * env stride * element size must stay below 2^31
     const int64_t lim = ((int64_t)1 << 31) / (BLOCK * (int64_t)sizeof(T));

@@ -14,6 +14,10 @@ template <typename T, class M> struct Ctx {
   T dt;        // solver step (obs_stepsize; == tau on the step path)
   T env_tau;   // self.tau (PMSM angle prediction)
   T adv_coef;  // PMSM: (deadtime + 0.5) * tau, folded in double on the host (pmsm_env.py:599-604)
+  // PMSM sim_ahead: jnp.linspace(0, tau * (K - 1), K) of the predicted angles (pmsm_env.py:719-722) — its end point
+  // tau * (K - 1) (folded in double on the host like the Python expression), K - 1 as a float and as an index
+  T lin_stop, lin_div;
+  int64_t lin_last;
   // PMSM saturated model only: LUT grids and the node-interleaved tables [n_d][n_q][8]
   const T* lut_gd;
   const T* lut_gq;

@@ -145,8 +145,14 @@ template <typename T> struct AheadAux {
   T eps0, prev_clip[2];  // prev_clip starts as the initial voltage buffer, so row 0 of the trajectory shows that buffer
 };
 
+// jnp.linspace(0, tau * (K - 1), K)[k] as JAX evaluates it (jax.numpy.linspace: start * (1 - s) + stop * s with s = k / (K - 1)
+// for k < K - 1, the end point itself for k == K - 1; start == 0 contributes +0). Wave-uniform: k and K are.
+template <typename T, class M> __device__ __forceinline__ T ahead_time(int64_t k, const Ctx<T, M>& c) {
+  return (k == c.lin_last) ? c.lin_stop : c.lin_stop * (T(k) / c.lin_div);
+}
+
 // One solver step of the raw ODE state, reference _ode_solver_simulate_ahead structure (SEM_AHEAD):
-// no wrap / clip of the carried state; PMSM clips with the predicted angle eps0 + (k*tau)*omega
+// no wrap / clip of the carried state; PMSM clips with the predicted angle eps0 + linspace(0, tau*(K-1), K)[k] * omega
 // (pmsm_env.py:719-722) and applies actions_dead[k] (:766-777).
 template <class M, int SOLVER, typename T>
 __device__ __forceinline__ void env_advance_raw(T (&st)[M::S], const T (&a)[M::A], const T (&a1)[M::A], int64_t k,
@@ -156,7 +162,7 @@ __device__ __forceinline__ void env_advance_raw(T (&st)[M::S], const T (&a)[M::A
   T uc[2] = {T(0), T(0)};
   bool dead = false;
   if constexpr (M::IS_PMSM) {
-    M::constraint(a, aux.eps0 + (T(k) * c.env_tau) * st[6], st[6], c, uc);
+    M::constraint(a, aux.eps0 + ahead_time(k, c) * st[6], st[6], c, uc);
     dead = c.P[6] > T(0);
     u[0] = dead ? aux.prev_clip[0] : uc[0];
     u[1] = dead ? aux.prev_clip[1] : uc[1];
@@ -172,7 +178,7 @@ __device__ __forceinline__ void env_advance_raw(T (&st)[M::S], const T (&a)[M::A
         u1[0] = (k1 == k) ? u[0] : uc[0];
         u1[1] = (k1 == k) ? u[1] : uc[1];
       } else {
-        M::constraint(a1, aux.eps0 + (T(k1) * c.env_tau) * st[6], st[6], c, u1);
+        M::constraint(a1, aux.eps0 + ahead_time(k1, c) * st[6], st[6], c, u1);
       }
     } else {
       u1[0] = denormalize(a1[0], c.amin[0], c.amax[0]);

@@ -10,7 +10,7 @@ Usage mirrors the reference package (README.md:15-33):
     observations, states, last_state = env.vmap_sim_ahead(state, actions, env.tau, env.tau)  # one persistent launch
 """
 from .core_env import CoreEnvironment
-from .envs import Acrobot, CartPole, FluidTank, MassSpringDamper, MotorVariant, Pendulum, PMSM, prepare_pmsm_lut
+from .envs import Acrobot, CartPole, FluidTank, MassSpringDamper, MotorVariant, Pendulum, PMSM, load_pmsm_lut, prepare_pmsm_lut
 from .registration import EnvironmentRegistry
 from .gym_wrapper import GymWrapper
 from .solvers import Euler, RK4, Tsit5
@@ -19,7 +19,7 @@ from .utils import MinMaxNormalization, dump_sim_properties_to_json, load_sim_pr
 from . import random, tree, utils
 
 __all__ = [
-    "CoreEnvironment", "Acrobot", "CartPole", "FluidTank", "MassSpringDamper", "Pendulum", "PMSM", "MotorVariant", "prepare_pmsm_lut",
+    "CoreEnvironment", "Acrobot", "CartPole", "FluidTank", "MassSpringDamper", "Pendulum", "PMSM", "MotorVariant", "prepare_pmsm_lut", "load_pmsm_lut",
     "EnvironmentRegistry", "GymWrapper", "Stepper", "Euler", "RK4", "Tsit5", "MinMaxNormalization", "dump_sim_properties_to_json",
     "load_sim_properties_from_json", "random", "tree", "utils",
 ]

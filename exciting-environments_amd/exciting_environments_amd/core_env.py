@@ -266,7 +266,29 @@ class CoreEnvironment(ABC):
             flag = torch.full(shape, active, dtype=torch.bool, device=self.device)
             if len(self._flag_cache) < 64:
                 self._flag_cache[key] = flag
-        return self.Additions(solver_state=None, active_solver_state=flag)
+        return self.Additions(solver_state=self._solver_state_leaf(shape), active_solver_state=flag)
+
+    # number of ODE variables the reference hands to diffrax (y0 tuples, e.g. pendulum_env.py:175; PMSM integrates
+    # (i_d, i_q, eps) only, pmsm_env.py:555): the arity of the FSAL derivative in the solver state
+    N_ODE: Optional[int] = None
+
+    def _solver_state_leaf(self, shape):
+        """Additions.solver_state with the reference's pytree structure (e.g. pendulum_env.py:177-192, 249-251, 289-290):
+        None for Euler (diffrax.Euler has no solver state) and the RK4 extension; for Tsit5 the pair diffrax's FSAL Runge-Kutta
+        keeps, (first_step, f0) with f0 a tuple shaped like the ODE state — filled with NaN in EVERY state. The reference
+        holds NaN there after a reset too (`tree_map(lambda x: x * jnp.nan, solver_state)`) and diffrax-internal values after
+        a step, which nothing but diffrax's own step reads; the fixed-step kernels need none of it (parity of the structure,
+        not of those values; diffrax's source is not in the container)."""
+        if not getattr(self._solver, "fsal", False):
+            return None
+        key = ("solver_state", tuple(shape))
+        leaf = self._flag_cache.get(key)
+        if leaf is None:
+            leaf = self._nan(tuple(shape))
+            if len(self._flag_cache) < 64:
+                self._flag_cache[key] = leaf
+        n = self.N_ODE if self.N_ODE is not None else len(self.STATE_FIELDS)
+        return (leaf, tuple(leaf for _ in range(n)))
 
     def _random_norm_state(self, rng, shape):
         """Random normalised initial state (e.g. pendulum_env.py:270-276). `rng` is either a key tensor ([2] / [B, 2]
@@ -985,16 +1007,14 @@ class CoreEnvironment(ABC):
             slowest, tried = t_ref, []
             pkey = (B, rows, OW, S, len(rd))
             known = self._placement_best.get(pkey)
-            if known is not None:
-                slowest = max(slowest, known / self._PLACEMENT_ACCEPT * 0.999)  # what was fast before is the bar now
             for _ in range(self._PLACEMENT_TRIES):
                 base = block.data_ptr()
                 t = self._time_pattern(rd, rd_rs, obs_w + [base + j * rows * rb for j in range(S)], obs_rs + [rb] * S, rb, prow,
                                        stream)
                 tried.append((t, block))
                 slowest = max(slowest, t)
-                # a later set of the same shape should also match the best placement an earlier set of this environment found
-                good = min(x for x, _ in tried) <= self._PLACEMENT_ACCEPT * slowest and (known is None or t <= 1.03 * known)
+                # a later set of the same shape has to match the best placement an earlier set of this environment found
+                good = (t <= 1.03 * known) if known is not None else (min(x for x, _ in tried) <= self._PLACEMENT_ACCEPT * slowest)
                 if good or len(tried) == self._PLACEMENT_TRIES:
                     break
                 try:  # the rejected block stays allocated while the next one is made, so that it lands somewhere else

@@ -29,8 +29,9 @@ def _dc(name, field_names, doc):
 
 @dataclass
 class _Additions:
-    """Dataclass containing additional information for simulation (e.g. pendulum_env.py:123-128). The fixed-step
-    kernels carry no solver state, so `solver_state` is always None."""
+    """Dataclass containing additional information for simulation (e.g. pendulum_env.py:123-128). `solver_state` has the
+    reference's structure for the chosen solver (None for Euler; a NaN-filled (first_step, f0) pair for Tsit5 —
+    CoreEnvironment._solver_state_leaf); the fixed-step kernels themselves carry no solver state."""
 
     solver_state: Any
     active_solver_state: Any
@@ -259,14 +260,42 @@ def prepare_pmsm_lut(pmsm_lut: dict):
     return grid_d, grid_q, tables
 
 
+LUT_FILE_NAMES = {"BRUSA": "LUT_BRUSA_jax_grad.mat", "SEW": "LUT_SEW_jax_grad.mat"}
+
+
+def load_pmsm_lut(motor_variant, path=None) -> dict:
+    """The motor's table file as the reference loads it (pmsm/motor_parameters.py:94,121: ``loadmat(<package>/LUT_<motor>_
+    jax_grad.mat)``): a dict with i_d_vec, i_q_vec and the six (n_iq, n_id) tables. `path` is the file itself or a directory
+    that holds it; without it the directory named by the environment variable EXCENV_PMSM_LUT_DIR and then
+    ``<this package>/data`` are searched (the repository keeps the reference's two files as fixtures under tests/golden/pmsm)."""
+    import os
+
+    from scipy.io import loadmat
+
+    name = LUT_FILE_NAMES[motor_variant.value if isinstance(motor_variant, MotorVariant) else str(motor_variant)]
+    tried = []
+    for cand in (path, os.environ.get("EXCENV_PMSM_LUT_DIR"), os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")):
+        if not cand:
+            continue
+        f = os.path.join(cand, name) if os.path.isdir(cand) else cand
+        tried.append(f)
+        if os.path.isfile(f):
+            d = loadmat(f)
+            return {k: v for k, v in d.items() if not k.startswith("__")}
+    raise ValueError(
+        f"PMSM(saturated=True): the look-up table file {name} was not found (looked at: {tried or 'nowhere'}). Pass "
+        "pmsm_lut_path=<file or directory>, set EXCENV_PMSM_LUT_DIR, or pass the tables themselves as pmsm_lut=<dict>.")
+
+
 class PMSM(CoreEnvironment):
     """Permanent-magnet synchronous motor in dq coordinates with voltage-hexagon clip and one-step action dead time
     (pmsm/pmsm_env.py:115-267). ``saturated=False``: linear model (`linear_ode`). ``saturated=True``: flux linkages and
-    differential inductances from look-up tables (`nonlinear_ode`); pass the tables as ``pmsm_lut=`` (a dict with the
-    reference's keys, e.g. ``scipy.io.loadmat`` of the reference's LUT file) — the motor data files themselves are not
-    redistributed here."""
+    differential inductances from look-up tables (`nonlinear_ode`): the motor variant's table file is loaded like the reference
+    does (``load_pmsm_lut``; ``pmsm_lut_path=`` names the file or its directory), or the tables are passed as ``pmsm_lut=``
+    (a dict with the reference's keys)."""
 
     ENV_ID = 5
+    N_ODE = 3  # the reference integrates y = (i_d, i_q, eps) (pmsm_env.py:555)
     STATE_FIELDS = ("u_d_buffer", "u_q_buffer", "epsilon", "i_d", "i_q", "torque", "omega_el")
     ACTION_FIELDS = ("u_d", "u_q")
     PARAM_FIELDS = ("p", "r_s", "l_d", "l_q", "psi_p", "u_dc", "deadtime")
@@ -287,7 +316,8 @@ class PMSM(CoreEnvironment):
     def __init__(self, batch_size: int = 8, saturated=False, motor_variant: MotorVariant = MotorVariant.DEFAULT,
                  physical_normalizations: dict = None, action_normalizations: dict = None,
                  soft_constraints: Callable = None, static_params: dict = None, control_state: list = None,
-                 solver=Euler(), tau: float = 1e-4, dtype=torch.float32, device=None, pmsm_lut: dict = None):
+                 solver=Euler(), tau: float = 1e-4, dtype=torch.float32, device=None, pmsm_lut: dict = None,
+                 pmsm_lut_path: str = None):
         self._lut_host = None
         motor_params = motor_variant.get_params()
         if saturated:
@@ -296,12 +326,8 @@ class PMSM(CoreEnvironment):
                     f"MotorVariant '{motor_variant.value}' is not allowed for saturated LUTs. "
                     "Use a specific motor variant. DEFAULT is only valid for saturated=False."
                 )
-            if pmsm_lut is None:
-                raise ValueError(
-                    "PMSM(saturated=True) needs the look-up tables: pass pmsm_lut=<dict with i_d_vec, i_q_vec, L_dd, L_dq, "
-                    "L_qd, L_qq, Psi_d, Psi_q>, e.g. scipy.io.loadmat of the reference's LUT_<motor>_jax_grad.mat "
-                    "(the motor data files are not redistributed with this package)."
-                )
+            if pmsm_lut is None:  # pmsm/motor_parameters.py:94,121 + pmsm_env.py:164-175: the variant's own table file
+                pmsm_lut = load_pmsm_lut(motor_variant, pmsm_lut_path)
             self._lut_host = prepare_pmsm_lut(pmsm_lut)
             self.pmsm_lut = pmsm_lut
             for k in ("l_d", "l_q", "psi_p"):  # pmsm_env.py:171-174

@@ -6,6 +6,9 @@ diffrax objects cannot exist here). Fixed step only, like every call site in the
 class _Solver:
     id = -1
     name = "?"
+    # diffrax keeps a solver state only for FSAL ("first same as last") Runge-Kutta methods: (first_step, f0) with f0 shaped like
+    # the ODE state; Euler's and the RK4 extension's is None. The environments mirror that in Additions.solver_state.
+    fsal = False
 
     def __repr__(self):
         return f"{type(self).__name__}()"
@@ -33,3 +36,4 @@ class Tsit5(_Solver):
     """Tsitouras 5(4), 5th-order solution at fixed step (error estimate unused, as under ConstantStepSize)."""
 
     id, name = 2, "tsit5"
+    fsal = True

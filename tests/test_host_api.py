@@ -169,6 +169,35 @@ def test_reset(env_type):
         env.vmap_reset(initial_state=state.physical_state)
 
 
+@pytest.mark.parametrize("env_type", envs_to_test)
+def test_solver_state_leaf_has_the_reference_structure(env_type):
+    """Additions.solver_state (e.g. pendulum_env.py:177-192, 289-290): None for Euler (diffrax.Euler keeps no solver state) and
+    the RK4 extension, a NaN-filled (first_step, f0) pair for Tsit5 with f0 shaped like the ODE state the reference integrates
+    (PMSM: (i_d, i_q, eps), pmsm_env.py:555) — so that the pytree structure of a State does not depend on where it came from
+    (reset, single-env reset, initial_state round trip)."""
+    import exciting_environments_amd as ex
+    from exciting_environments_amd.tree import tree_flatten, tree_structure
+
+    B = 3
+    n_ode = {"PMSM": 3}.get(env_type.name, None)
+    for solver, fsal in ((ex.Euler(), False), (ex.RK4(), False), (ex.Tsit5(), True)):
+        env = env_type.make(batch_size=B, device="cpu", solver=solver)
+        _, state = env.vmap_reset()
+        ss = state.additions.solver_state
+        if not fsal:
+            assert ss is None
+            continue
+        n = n_ode or len(env.STATE_FIELDS)
+        assert isinstance(ss, tuple) and len(ss) == 2 and isinstance(ss[1], tuple) and len(ss[1]) == n
+        leaves, _ = tree_flatten(ss)
+        assert len(leaves) == n + 1 and all(tuple(l.shape) == (B,) and bool(torch.isnan(l).all()) for l in leaves)
+        _, single = env.reset(env.env_properties)
+        assert tree_structure(single) == tree_structure(state)
+        assert all(tuple(l.shape) == () for l in tree_flatten(single.additions.solver_state)[0])
+        _, again = env.vmap_reset(initial_state=state)
+        assert tree_structure(again) == tree_structure(state)
+
+
 def test_default_reset_states_in_physical_units():
     """SURVEY.md §8 a11."""
     val = lambda env, n: float(getattr(env.vmap_reset()[1].physical_state, n)[0])
