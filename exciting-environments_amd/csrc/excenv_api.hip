@@ -202,9 +202,11 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
   const int nc = control ? control->n_control : 0;
   const int64_t wbytes = dtype == EXCENV_F64 ? 8 : 4;
   // one decision for the whole call: fused env-major kernel / workspace + transposes / generic strides
-  const bool fused_em = B > 0 && K > 0 && aligned16(obs_traj) &&
+  // (the fused kernel reads the action array in whole 16-byte pieces: it must start on one and consist of whole ones —
+  // otherwise the generic-stride / workspace paths take the call)
+  const bool fused_em = B > 0 && K > 0 && aligned16(obs_traj) && aligned16(actions) && (B * K * (int64_t)t->A * wbytes) % 16 == 0 &&
                         em_fused_eligible(opts->env_major_mode, action_layout, traj_layout, substeps, gym != nullptr, t->A, t->S,
-                                          (size_t)wbytes);
+                                          t->O, (size_t)wbytes);
   const int64_t need = excenv_sim_ahead_workspace_bytes(env, dtype, B, K, substeps, nc, action_layout, traj_layout,
                                                         state_traj != nullptr);
   const bool via_ws = !fused_em && !gym && workspace && need > 0 && workspace_bytes >= need && B > 0 &&

@@ -56,9 +56,9 @@ struct SimCall {
 // The fused env-major kernel applies when both layouts are env-major, substeps == 1, the caller did not opt out, no gym
 // trajectories are requested and the time tile fits LDS. Decided once per call (excenv_api.hip) and handed to launch_sim.
 static inline bool em_fused_eligible(int em_mode, int action_layout, int traj_layout, int32_t substeps, bool with_gym,
-                                     int A, int S, size_t elem) {
+                                     int A, int S, int O, size_t elem) {
   return em_mode != 1 && action_layout == EXCENV_LAYOUT_ENV_MAJOR && traj_layout == EXCENV_LAYOUT_ENV_MAJOR &&
-         substeps == 1 && !with_gym && (elem == 8 ? em_lds_elems<double>(A, S) : em_lds_elems<float>(A, S)) * elem <= 150 * 1024;
+         substeps == 1 && !with_gym && (elem == 8 ? em_lds_elems<double>(A, S, O) : em_lds_elems<float>(A, S, O)) * elem <= 150 * 1024;
 }
 
 struct TrajGymCall {
@@ -434,7 +434,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
 
   if (sc.em_mode == 2) {  // decided by the caller (em_fused_eligible): fused env-major kernel, one wave per 64 envs,
                           // TK steps staged in LDS, per-env contiguous runs written out
-    const size_t lds = em_lds_elems<T>(M::A, M::S) * sizeof(T);
+    const size_t lds = em_lds_elems<T>(M::A, M::S, M::O) * sizeof(T);
     const dim3 grid((unsigned)((sc.B + EM_LANES - 1) / EM_LANES)), block(EM_LANES);
 #define EXCENV_EM_CASE(SOLV)                                                                                             \
   case SOLV:                                                                                                             \
