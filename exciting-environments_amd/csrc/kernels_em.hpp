@@ -37,6 +37,12 @@ namespace excenv {
 constexpr int EM_LANES = 64;  // one wave per workgroup
 static_assert((EXCENV_EM_TK & (EXCENV_EM_TK - 1)) == 0 && EXCENV_EM_TK >= 2 && EXCENV_EM_TK <= EM_LANES,
               "EXCENV_EM_TK must be a power of two in [2, 64]");
+// One wave per workgroup: LDS instructions of a wave execute in issue order, so a value one lane wrote is visible to the lane
+// that reads it later in program order — no s_barrier and no s_waitcnt lgkmcnt(0) (which __syncthreads() implies) are needed,
+// only the compiler must not reorder the accesses.
+static_assert(EM_LANES == 64, "the fused env-major kernel relies on a single wave64 per workgroup");
+__device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
+
 template <typename T> __host__ __device__ constexpr int em_tk() { return sizeof(T) == 4 ? EXCENV_EM_TK : EXCENV_EM_TK / 2; }
 
 // LDS elements per wave: the per-lane action line (128 bytes + one 16-byte pad), the ring of saved states, one round of
@@ -172,7 +178,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
         }
         // the (env, step) offset of every row of the round, for the lanes that will store its pieces
         row_off[lane] = valid ? row_el : 0xffffffffu;
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int i = 0; i < PR; ++i) {
           const int p = lane + EM_LANES * i;  // piece index in round order == memory order within each environment's run
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
           for (int j = 0; j < S; ++j) (ka.straj[j] + b0 * (N + 1))[row_el] = v[j];
         }
       }
-      __syncthreads();  // staging buffer / row_off free for the next round
+      wave_sync();  // staging buffer / row_off free for the next round
     }
   };
 
@@ -268,7 +274,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
     }
 #pragma unroll
     for (int j = 0; j < S; ++j) tst[(j * EM_LANES + lane) * LDS_ + slot] = sv[j];
-    __syncthreads();
+    wave_sync();
     // environments whose window ends with step n (or with the trajectory)
     const bool due = active && ((((my_ph + (unsigned)slot + 1u) % TK) == 0u) || n == N);
     unsigned long long mask = __ballot(due);
