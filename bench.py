@@ -138,7 +138,7 @@ def cpu_baseline(args, reg, solver, dtype, tau, Kc):
 
     name = ORACLE_NAME[reg]
     npdt = np.float32 if dtype == torch.float32 else np.float64
-    Bc = 1 << 16
+    Bc = 1 << 20  # B = 2^20 (chunks of Kc steps chained until ~cpu_seconds; 1000 steps = 10 chunks of 100)
     from exciting_environments_amd import EnvironmentRegistry
 
     env = getattr(EnvironmentRegistry, reg).make(batch_size=Bc, tau=tau, dtype=dtype, device="cpu")
@@ -172,7 +172,7 @@ def cpu_baseline(args, reg, solver, dtype, tau, Kc):
     return {
         "value": Bc * Kc * reps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
         "sample": f"oracle/liboracle.so (C+OpenMP restatement, env-major layout) {name} {solver} "
-                  f"{np.dtype(npdt).name} B=2^16 x {Kc} steps x {reps} chained chunks, {el:.1f} s",
+                  f"{np.dtype(npdt).name} B=2^20 x {Kc} steps x {reps} chained chunks, {el:.1f} s",
     }
 
 

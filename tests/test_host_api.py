@@ -429,3 +429,23 @@ def test_reference_import_paths():
 
     assert (Acrobot, CartPole, FluidTank, MassSpringDamper, Pendulum, PMSM, MotorVariant) == (
         ex.Acrobot, ex.CartPole, ex.FluidTank, ex.MassSpringDamper, ex.Pendulum, ex.PMSM, ex.MotorVariant)
+
+
+def test_headline_loop_stays_inside_the_instruction_cache():
+    """Guard rail (tools/loop_code_size.py): the K loop of the headline kernel — PMSM Euler fp32, V = 4, two unrolled solver
+    steps x 4 environments per lane — is the largest piece of code that must stay resident in the 64 KB instruction cache for
+    the headline number; anything that grows it past 60 KB fails here, at build time, instead of showing up as a slow GPU run."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("loop_code_size", os.path.join(ROOT, "tools", "loop_code_size.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    spans = mod.loop_spans()
+    assert mod.HEADLINE in spans, "headline instantiation missing from the library"
+    loop, size = spans[mod.HEADLINE]
+    assert 8 * 1024 < loop <= 60 * 1024, f"headline K loop is {loop} bytes"
+    # the C2 / C4 kernels (pendulum Euler fp32, mass-spring-damper Tsit5 fp64) are far below it
+    small = [v[0] for k, v in spans.items() if ("Pendulum" in k or "MassSpringDamper" in k) and "sim_ahead_kernel" in k]
+    assert small and max(small) <= 60 * 1024

@@ -67,7 +67,11 @@ for f in find("trace", "*kernel_trace.csv"):
         lines += ["## dispatch resources (kernel_trace.csv)", "", "| kernel | VGPR | accum VGPR | SGPR | LDS | scratch | workgroup | grid |", "|---|---|---|---|---|---|---|---|"]
         for n, r in seen.items():
             lines.append(f"| `{n[:90]}` | {r.get('VGPR_Count')} | {r.get('Accum_VGPR_Count')} | {r.get('SGPR_Count')} | {r.get('LDS_Block_Size')} | {r.get('Scratch_Size')} | {r.get('Workgroup_Size')} | {r.get('Grid_Size')} |")
-        lines.append("")
+        lines += ["", "Units of this table: rocprofv3's `VGPR_Count` on gfx950 is HALF the registers a wave64 lane is allocated — the "
+                  "headline kernel compiles to 198 VGPRs (`-Rpass-analysis=kernel-resource-usage`, `profiles/*_loop_isa.md`), the "
+                  "allocation granule rounds that to 208, the trace shows 104; `SGPR_Count` is the allocated block (112), not the 93 "
+                  "the kernel uses; `LDS_Block_Size` is in granules. 512 registers per SIMD lane / 208 = two resident waves per "
+                  "SIMD; the SQ section below gives the measured residency.", ""]
 
 # ---- PMC ---------------------------------------------------------------------------------------
 pmc = {}
@@ -139,6 +143,11 @@ if sq:
             lines.append(f"| SQ_WAIT_ANY / SQ_WAVE_CYCLES (wave parked on s_waitcnt) | {per['SQ_WAIT_ANY'] / per['SQ_WAVE_CYCLES']:.3f} |")
         if "SQ_ACTIVE_INST_VALU" in per and "SQ_WAVE_CYCLES" in per and per["SQ_WAVE_CYCLES"] > 0:
             lines.append(f"| SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES | {per['SQ_ACTIVE_INST_VALU'] / per['SQ_WAVE_CYCLES']:.3f} |")
+        if per.get("GRBM_GUI_ACTIVE", 0) > 0 and per.get("SQ_WAVE_CYCLES", 0) > 0:
+            # SQ_WAVE_CYCLES counts quad-cycles of resident waves summed over the chip, GRBM_GUI_ACTIVE busy cycles summed over the
+            # 8 XCDs: resident waves per SIMD, averaged over the launch = 4 * SQ_WAVE_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
+            occ = 4.0 * per["SQ_WAVE_CYCLES"] / (1024.0 * per["GRBM_GUI_ACTIVE"] / 8.0)
+            lines.append(f"| measured residency: 4 x SQ_WAVE_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = waves per SIMD, launch average | {occ:.2f} |")
         lines.append("")
 open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
