@@ -266,22 +266,31 @@ template <class M, typename T, int SOLVER, bool GENERAL, int V>
 __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
   static_assert(!(GENERAL && V > 1), "vectorised lanes share one uniform property set");
+  // Observation rows wider than 16 bytes (PMSM: 32 B in fp32, 64 B in fp64; the 4-column environments in fp64): one row per
+  // lane would leave as 16-byte stores 32 / 64 bytes apart — every store instruction of the wave half / quarter dense. Those
+  // rows pass through an LDS staging area of the wave instead and leave as 64 CONSECUTIVE 16-byte pieces per instruction
+  // (1 KiB), like the trajectory kernels' stores. Lanes past the batch end stay alive on this path: they carry pieces of
+  // other lanes' rows.
+  constexpr int VW = 16 / (int)sizeof(T);
+  constexpr bool DENSE = !GENERAL && V == 1 && (O % VW) == 0 && (O / VW) > 1;
   const int64_t blk0 = (int64_t)blockIdx.x * (BLOCK * V);
   const unsigned lane_env = threadIdx.x * V;
   const int64_t i = blk0 + lane_env;
   Ctx<T, M> c;
   load_ctx<GENERAL, T, M, false>(c, ka.kp, (i < ka.B) ? i : 0, ka.dt, ka.env_tau, ka.adv_coef);  // one step: plain division
   stage_lut<M, T>(c, ka.kp);
-  if (i >= ka.B) return;
+  const bool live = i < ka.B;
+  if (!DENSE && !live) return;
+  const int64_t il = live ? i : ka.B - 1;  // DENSE: a lane past the end re-reads the last environment and stores nothing of its own
   T st[V][S], a[V * A], ob[V * O];
 #pragma unroll
   for (int j = 0; j < S; ++j) {
     T tmp[V];
-    load_v<T, V>(ka.state_in[j] + blk0 + lane_env, tmp);
+    load_v<T, V>(ka.state_in[j] + il, tmp);
 #pragma unroll
     for (int v = 0; v < V; ++v) st[v][j] = tmp[v];
   }
-  load_row<T, V * A>(ka.action + blk0 * A + lane_env * A, a);
+  load_row<T, V * A>(ka.action + il * A, a);
 #pragma unroll
   for (int v = 0; v < V; ++v) {
     T av[A], ov[O];
@@ -292,14 +301,38 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
 #pragma unroll
     for (int q = 0; q < O; ++q) ob[v * O + q] = ov[q];
   }
+  if (live) {
 #pragma unroll
-  for (int j = 0; j < S; ++j) {
-    T tmp[V];
+    for (int j = 0; j < S; ++j) {
+      T tmp[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) tmp[v] = st[v][j];
-    store_v<T, V>(ka.state_out[j] + blk0 + lane_env, tmp);
+      for (int v = 0; v < V; ++v) tmp[v] = st[v][j];
+      store_v<T, V>(ka.state_out[j] + i, tmp);
+    }
   }
-  if constexpr (!GENERAL) {
+  if constexpr (DENSE) {
+    constexpr int PR = O / VW;  // 16-byte pieces per row
+    __shared__ __align__(16) T stage[BLOCK * O];
+    const unsigned wave = threadIdx.x / 64u, lane = threadIdx.x % 64u;
+    T* const ws = stage + wave * 64u * O;  // this wave's 64 rows; only this wave touches them: LDS operations of one wave execute
+#pragma unroll                             // in issue order, so a compiler fence is all the synchronisation needed
+    for (int q = 0; q < O; q += VW) {
+      T v[VW];
+#pragma unroll
+      for (int h = 0; h < VW; ++h) v[h] = ob[q + h];
+      store_v<T, VW>(ws + lane * O + q, v);
+    }
+    asm volatile("" ::: "memory");
+    const int64_t row0 = blk0 + wave * 64u;  // first environment of the wave
+    T* const wobs = ka.obs + row0 * O;
+#pragma unroll
+    for (int k = 0; k < PR; ++k) {
+      const unsigned p = lane + 64u * k;  // piece index == memory order
+      T v[VW];
+      load_v<T, VW>(ws + p * VW, v);
+      if (row0 + (int64_t)(p / PR) < ka.B) store_v<T, VW>(wobs + p * VW, v);
+    }
+  } else if constexpr (!GENERAL) {
     store_row<T, V * O>(ka.obs + blk0 * O + lane_env * O, ob);
   } else {
     T rref[EXCENV_MAX_CONTROL];

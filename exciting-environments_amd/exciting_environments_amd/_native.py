@@ -196,6 +196,57 @@ def stream_pattern(read_ptrs, read_row_strides, write_ptrs, write_row_strides, r
         _check(rc, "excenv_stream_pattern")
 
 
+_hip = None
+
+
+def _hip_runtime():
+    """The HIP runtime torch already loaded (only hipMalloc / hipFree are used: spacer allocations that must not go through
+    torch's caching allocator, core_env.py trajectory placement)."""
+    global _hip
+    if _hip is None:
+        # the very file this process has mapped (torch ships its own copy): opening another copy would start a second runtime
+        loaded = None
+        try:
+            with open("/proc/self/maps") as f:
+                for line in f:
+                    if "libamdhip64" in line:
+                        loaded = line.split()[-1]
+                        break
+        except OSError:
+            loaded = None
+        for name in ([loaded] if loaded else []):
+            try:
+                h = ctypes.CDLL(name)
+                h.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+                h.hipMalloc.restype = ctypes.c_int
+                h.hipFree.argtypes = [ctypes.c_void_p]
+                h.hipFree.restype = ctypes.c_int
+                _hip = h
+                break
+            except OSError:
+                continue
+        if _hip is None:
+            _hip = False
+    return _hip or None
+
+
+def raw_malloc(nbytes: int):
+    """hipMalloc outside torch's allocator; None when it fails (out of memory) or the runtime cannot be reached."""
+    h = _hip_runtime()
+    if h is None:
+        return None
+    p = ctypes.c_void_p()
+    if h.hipMalloc(ctypes.byref(p), int(nbytes)) != 0 or not p.value:
+        return None
+    return p.value
+
+
+def raw_free(ptr):
+    h = _hip_runtime()
+    if h is not None and ptr:
+        h.hipFree(ctypes.c_void_p(ptr))
+
+
 def env_dims(env_id: int):
     S, A, O, P = (ctypes.c_int32() for _ in range(4))
     _check(lib().excenv_env_dims(env_id, ctypes.byref(S), ctypes.byref(A), ctypes.byref(O), ctypes.byref(P)), "excenv_env_dims")

@@ -968,66 +968,52 @@ class CoreEnvironment(ABC):
         """Drop the pooled (dead) trajectory output sets so that their memory returns to torch's allocator."""
         self._traj_sets = []
 
-    def _time_pattern(self, read_ptrs, read_rs, write_ptrs, write_rs, row_bytes, rows, stream):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        _native.stream_pattern(read_ptrs, read_rs, write_ptrs, write_rs, row_bytes, rows, stream)  # warm
-        ev[0].record()
-        _native.stream_pattern(read_ptrs, read_rs, write_ptrs, write_rs, row_bytes, rows, stream)
-        ev[1].record()
-        ev[1].synchronize()
-        return float(ev[0].elapsed_time(ev[1]))
+    _PLACEMENT_SPACER_BYTES = 16 << 30  # a rejected block + this much memory stay allocated while the next block is made
 
-    def _place_state_block(self, obs_buf, B, rows, OW, S, isz, actions):
+    def _place_state_block(self, obs_buf, B, rows, OW, S, isz, time_launch):
         """A [S, rows, B] block for the state leaves of a new set whose traffic, together with the observations', does not fall
-        into one physical region (see above). Returns (block, diagnostics)."""
+        into one physical region (see above). `time_launch(block)` runs the trajectory launch of the current call into
+        (obs_buf, block) and returns its time in ms. Returns (block, diagnostics)."""
         dt, dev = self.dtype, self.device
         block = torch.empty((S, rows, B), dtype=dt, device=dev)
         nbytes = (OW + S) * rows * B * isz
-        if (self.trajectory_placement != "auto" or nbytes < self._PLACED_TRAJ_BYTES or (B * isz) % 16 or rows < 8 or S > OW
+        if (self.trajectory_placement != "auto" or time_launch is None or nbytes < self._PLACED_TRAJ_BYTES
                 or torch.cuda.is_current_stream_capturing()):
             return block, None
-        stream = _native._raw_stream(dev)
-        rb, prow = B * isz, rows - 2
-        ob = obs_buf.data_ptr()
-        rd, rd_rs = [], []
-        if actions is not None:  # lane-major [K, A, B] actions: the read streams of the launch
-            A = self.action_dim
-            rd = [actions.data_ptr() + c * rb for c in range(A)]
-            rd_rs = [A * rb] * A
-            prow = min(prow, actions.shape[1])
-        obs_w, obs_rs = [ob + c * rb for c in range(OW)], [OW * rb] * OW
-        W = OW + S
-        with _native._on_device(dev):
-            # Reference level: every stream inside ONE buffer read as [rows'][OW + S][B] (no address written twice) — at any time
-            # the launch's traffic then lies within a few hundred MB, i.e. in one region wherever that buffer is contiguous in
-            # physical memory. It is only a reference, not a guarantee (a buffer backed by scattered pages is "fast" even so):
-            # a candidate is accepted when it is clearly faster than the SLOWEST time seen so far, references included.
-            prow1 = min(prow, rows * OW // W)
-            t_ref = self._time_pattern(rd, rd_rs, [ob + q * rb for q in range(W)], [W * rb] * W, rb, prow1, stream) * prow / prow1
-            slowest, tried = t_ref, []
-            pkey = (B, rows, OW, S, len(rd))
-            known = self._placement_best.get(pkey)
-            for _ in range(self._PLACEMENT_TRIES):
-                base = block.data_ptr()
-                t = self._time_pattern(rd, rd_rs, obs_w + [base + j * rows * rb for j in range(S)], obs_rs + [rb] * S, rb, prow,
-                                       stream)
-                tried.append((t, block))
-                slowest = max(slowest, t)
-                # a later set of the same shape has to match the best placement an earlier set of this environment found
-                good = (t <= 1.03 * known) if known is not None else (min(x for x, _ in tried) <= self._PLACEMENT_ACCEPT * slowest)
-                if good or len(tried) == self._PLACEMENT_TRIES:
-                    break
-                try:  # the rejected block stays allocated while the next one is made, so that it lands somewhere else
-                    block = torch.empty((S, rows, B), dtype=dt, device=dev)
-                except torch.OutOfMemoryError:
-                    break
+        pkey = (B, rows, OW, S)
+        known = self._placement_best.get(pkey)
+        tried, spacers = [], []
+        for k in range(self._PLACEMENT_TRIES):
+            t = time_launch(block)
+            tried.append((t, block))
+            times = [x for x, _ in tried]
+            # enough when this block matches the best placement an earlier set of this shape found, or when two placements
+            # have been seen and the better one is clearly (7 %) faster than the other: the two levels have shown themselves
+            if known is not None:
+                good = t <= 1.03 * known
+            else:
+                good = len(times) >= 2 and min(times) <= self._PLACEMENT_ACCEPT * max(times)
+            if good or k == self._PLACEMENT_TRIES - 1:
+                break
+            # the rejected block AND a spacer (hipMalloc outside torch's cache, freed below) stay allocated while the next block
+            # is made, so that it lands >= 16 GiB further on
+            with _native._on_device(dev):
+                sp = _native.raw_malloc(max(self._PLACEMENT_SPACER_BYTES - S * rows * B * isz, 1 << 20))
+            if sp is not None:
+                spacers.append(sp)
+            try:
+                block = torch.empty((S, rows, B), dtype=dt, device=dev)
+            except torch.OutOfMemoryError:
+                break
         t_best, best = min(tried, key=lambda tb: tb[0])
         self._placement_best[pkey] = t_best if known is None else min(known, t_best)
-        gbs = lambda t: (len(rd) + OW + S) * rb * prow / t / 1e6
-        diag = {"one_buffer_reference_ms": t_ref, "candidate_ms": [t for t, _ in tried],
-                "chosen": [t for t, _ in tried].index(t_best), "clearly_faster_than_slowest_seen": bool(t_best <= self._PLACEMENT_ACCEPT * slowest),
-                "rows": prow, "slowest_seen_gbs": gbs(slowest), "chosen_gbs": gbs(t_best)}
+        diag = {"candidate_ms": [round(t, 4) for t, _ in tried], "chosen": [t for t, _ in tried].index(t_best),
+                "best_known_ms_before": known, "spacer_gib": self._PLACEMENT_SPACER_BYTES / 2**30,
+                "what": "trajectory launch of the call timed into (observations, candidate state block); rejected blocks and a "
+                        "spacer stay allocated while the next candidate is made"}
         del tried, block
+        for sp in spacers:
+            _native.raw_free(sp)
         return best, diag
 
     def _traj_set_is_free(self, ts, stream) -> bool:
@@ -1039,7 +1025,7 @@ class CoreEnvironment(ABC):
             return False
         return [CoreEnvironment._storage_use_count(st._cdata) for st in ts.storages] == ts.use0
 
-    def _traj_set_for(self, B, rows, OW, S, want_states, last_e, isz, actions):
+    def _traj_set_for(self, B, rows, OW, S, want_states, last_e, isz, launch):
         dt, dev = self.dtype, self.device
         key = (B, rows, OW, S, want_states, dt)
         capturing = torch.cuda.is_current_stream_capturing()
@@ -1056,20 +1042,30 @@ class CoreEnvironment(ABC):
         ts.key = key
         ts.obs_buf = torch.empty((rows, OW, B), dtype=dt, device=dev)
         ts.placement = None
+        ts.lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
+        lb = ts.lbuf.data_ptr()
+        ts.last_ptrs = _native.ptr_array([lb + j * last_e * isz for j in range(S)])
+        ts.obs_ptr = ts.obs_buf.data_ptr()
         if want_states:
-            ts.st_buf, ts.placement = self._place_state_block(ts.obs_buf, B, rows, OW, S, isz, actions)
+            def time_launch(block):
+                ptrs = _native.ptr_array([block.data_ptr() + j * rows * B * isz for j in range(S)])
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                launch(ts.obs_ptr, ptrs, ts.last_ptrs)  # warm
+                ev[0].record()
+                launch(ts.obs_ptr, ptrs, ts.last_ptrs)
+                ev[1].record()
+                ev[1].synchronize()
+                return float(ev[0].elapsed_time(ev[1]))
+
+            ts.st_buf, ts.placement = self._place_state_block(ts.obs_buf, B, rows, OW, S, isz, time_launch if launch is not None else None)
             self.last_placement = ts.placement
             sb = ts.st_buf.data_ptr()
             ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (rows * B, 1, B)).unbind(0))
             ts.traj_ptrs = _native.ptr_array([sb + j * rows * B * isz for j in range(S)])
         else:
             ts.st_buf, ts.st_views, ts.traj_ptrs = None, None, None
-        ts.lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
         ts.observations = ts.obs_buf.permute(2, 0, 1)
         ts.last = tuple(ts.lbuf[:, :B].unbind(0))
-        ts.obs_ptr = ts.obs_buf.data_ptr()
-        lb = ts.lbuf.data_ptr()
-        ts.last_ptrs = _native.ptr_array([lb + j * last_e * isz for j in range(S)])
         ts.tens = (ts.observations,) + (ts.st_views or ()) + ts.last
         ts.storages = [t.untyped_storage() for t in ((ts.obs_buf, ts.lbuf) + ((ts.st_buf,) if want_states else ()))]
         ts.rc0 = ts.use0 = ts.stream = None
@@ -1113,6 +1109,18 @@ class CoreEnvironment(ABC):
         shared = (traj_e + S * last_e + ws_e) * isz <= self._SHARED_TRAJ_BYTES
         st_views = None
         ws_ptr = None
+        sem = _native.SEM_AHEAD if self.sim_ahead_semantics == "ahead" else _native.SEM_STEP
+        st_in_ptrs = _native._ptrs(st_in)
+
+        def launch(o_ptr, t_ptrs, l_ptrs):  # the trajectory launch of this call into the given output buffers
+            with _native._on_device(dev):
+                _native.sim_ahead_raw(self.ENV_ID, self._solver.id, 0 if dt is torch.float32 else 1, B, K, sub, ctypes.byref(props),
+                                      ctypes.byref(control) if control is not None else None, float(obs_stepsize), float(self.tau),
+                                      st_in_ptrs, actions.data_ptr() if K > 0 else None, a_layout, o_ptr,
+                                      t_ptrs if want_states else None, _native.LAYOUT_LANE_MAJOR, l_ptrs, sem, ws_ptr,
+                                      ws_bytes if ws_ptr is not None else 0, None if opts is None else ctypes.byref(opts),
+                                      _native._raw_stream(dev))
+
         if out is not None:
             # the caller hands back what an earlier call of the same shape returned: same buffers, no allocation
             observations, o_states, o_last = out
@@ -1150,21 +1158,13 @@ class CoreEnvironment(ABC):
             last_ptrs = _native.ptr_array([base + (traj_e + j * last_e) * isz for j in range(S)])
             obs_ptr = base
         else:
-            ts = self._traj_set_for(B, rows, OW, S, want_states, last_e, isz,
-                                    actions if (a_layout == _native.LAYOUT_LANE_MAJOR and sub == 1 and K > 0) else None)
-            observations, st_views, last = ts.observations, ts.st_views, ts.last
-            obs_ptr, traj_ptrs, last_ptrs = ts.obs_ptr, ts.traj_ptrs, ts.last_ptrs
             if ws_e:
                 ws = torch.empty(ws_e, dtype=dt, device=dev)  # stream-ordered: free to die when this function returns
                 ws_ptr = ws.data_ptr()
-        sem = _native.SEM_AHEAD if self.sim_ahead_semantics == "ahead" else _native.SEM_STEP
-        with _native._on_device(dev):
-            _native.sim_ahead_raw(self.ENV_ID, self._solver.id, 0 if dt is torch.float32 else 1, B, K, sub, ctypes.byref(props),
-                                  ctypes.byref(control) if control is not None else None, float(obs_stepsize), float(self.tau),
-                                  _native._ptrs(st_in), actions.data_ptr() if K > 0 else None, a_layout, obs_ptr,
-                                  traj_ptrs if want_states else None, _native.LAYOUT_LANE_MAJOR, last_ptrs, sem, ws_ptr,
-                                  ws_bytes if ws_ptr is not None else 0, None if opts is None else ctypes.byref(opts),
-                                  _native._raw_stream(dev))
+            ts = self._traj_set_for(B, rows, OW, S, want_states, last_e, isz, lambda o, t, l: launch(o, t, l))
+            observations, st_views, last = ts.observations, ts.st_views, ts.last
+            obs_ptr, traj_ptrs, last_ptrs = ts.obs_ptr, ts.traj_ptrs, ts.last_ptrs
+        launch(obs_ptr, traj_ptrs, last_ptrs)
         return observations, st_views, last, N
 
     def _traj_state(self, init_state, st_views, lead_shape, N):

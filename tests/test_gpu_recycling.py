@@ -253,7 +253,7 @@ def test_slot_recycling_really_engages_on_this_torch_build(gym):
     from exciting_environments_amd.core_env import CoreEnvironment
 
     assert CoreEnvironment._storage_use_count is not None and CoreEnvironment._tensor_use_count is not None
-    env, *_ = make_env("pendulum", 1024, torch.float32)
+    env = EnvironmentRegistry.PENDULUM.make(batch_size=1024, device="cuda:0")
     _, state = env.vmap_reset()
     act = torch.zeros((1024, 1), device=env.device)
     step = env.vmap_gym_step if gym else env.vmap_step
