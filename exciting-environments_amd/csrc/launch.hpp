@@ -432,6 +432,11 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     }
   }
 
+  if (sc.em_mode == 2 && !em_fused_eligible(0, sc.action_layout, sc.traj_layout, sc.substeps, sc.gym != nullptr, M::A, M::S, M::O,
+                                            sizeof(T))) {  // em_mode 2 is produced by excenv_sim_ahead_ws only; never trust it blindly
+    set_error("excenv_sim_ahead: internal error: fused env-major kernel selected for an ineligible call");
+    return EXCENV_EINVAL;
+  }
   if (sc.em_mode == 2) {  // decided by the caller (em_fused_eligible): fused env-major kernel, one wave per 64 envs,
                           // TK steps staged in LDS, per-env contiguous runs written out
     const size_t lds = em_lds_elems<T>(M::A, M::S, M::O) * sizeof(T);
@@ -498,7 +503,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     ka.o_wg = wg_off(sc.traj_layout, ka.o_sb, (N + 1) * OW * TILE);
     ka.s_wg = wg_off(sc.traj_layout, ka.s_sb, (N + 1) * TILE);
     if (ka.a_wg < 0 || ka.o_wg < 0 || ka.s_wg < 0) {
-      set_error("excenv_sim_ahead: tiled layout needs unbatched properties, no control columns, 16-byte aligned buffers and the %d-byte dtype", 4);
+      set_error("excenv_sim_ahead: tiled layout needs unbatched properties, no gym trajectories, 16-byte aligned buffers and the %d-byte dtype (control columns are filled by a second launch)", 4);
       return EXCENV_EUNSUPPORTED;
     }
   }

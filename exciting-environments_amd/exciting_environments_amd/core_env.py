@@ -38,6 +38,11 @@ def _is_scalar(x) -> bool:
     return _is_array(x) and x.ndim == 0
 
 
+# private fast accessors of torch when this build has them, the public (slower) API otherwise
+_cuda_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+_cuda_is_capturing = getattr(torch._C, "_cuda_isCurrentStreamCapturing", None) or torch.cuda.is_current_stream_capturing
+
+
 class CoreEnvironment(ABC):
     """Core structure of the provided environments (reference core_env.py:15-57).
 
@@ -634,16 +639,16 @@ class CoreEnvironment(ABC):
             control_ref = cc[4]
         props, _keep = self._props_for(self.env_properties, B)
         idx = dev.index
-        cur = torch._C._cuda_getDevice()
+        cur = _cuda_get_device()
         if idx is None:
             idx = cur
         if idx == cur:
             stream = _native.raw_stream(idx)
-            capturing = torch._C._cuda_isCurrentStreamCapturing()
+            capturing = _cuda_is_capturing()
         else:
             with torch.cuda.device(dev):
                 stream = _native.raw_stream(idx)
-                capturing = torch._C._cuda_isCurrentStreamCapturing()
+                capturing = _cuda_is_capturing()
         sl = None if capturing else self._slots[gym]
         if sl is not None:
             i = sl.i
@@ -1108,6 +1113,7 @@ class CoreEnvironment(ABC):
                 ws_e = up((ws_bytes + isz - 1) // isz)
         shared = (traj_e + S * last_e + ws_e) * isz <= self._SHARED_TRAJ_BYTES
         st_views = None
+        traj_ptrs = None
         ws_ptr = None
         sem = _native.SEM_AHEAD if self.sim_ahead_semantics == "ahead" else _native.SEM_STEP
         st_in_ptrs = _native._ptrs(st_in)

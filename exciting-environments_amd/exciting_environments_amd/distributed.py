@@ -77,6 +77,7 @@ class ObservationGatherer:
         self._stream = None
         self._event = None
         self._device = None
+        self._held = None  # the shard being gathered: kept referenced until wait()
 
     def _side_stream(self, device):
         if self._stream is None or self._stream.device != device:
@@ -113,6 +114,10 @@ class ObservationGatherer:
                 local.record_stream(side)
                 out.record_stream(side)
             self._event = side.record_event()
+            # record_stream only tells TORCH's allocator; the environments' own output pools (vmap_step slots, trajectory sets)
+            # recycle a buffer when nothing refers to it and the stream is the same — so the shard stays referenced here until
+            # wait() has ordered the consumer's stream behind the collective
+            self._held = local
         else:
             self._gather(local, out)
         return out
@@ -121,3 +126,4 @@ class ObservationGatherer:
         if self._event is not None:
             torch.cuda.current_stream(self._device).wait_event(self._event)
             self._event = None
+        self._held = None

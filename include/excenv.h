@@ -124,7 +124,9 @@ typedef struct {
 /* Per-call launch options (no reference counterpart; NULL = all defaults). Everything that shapes a launch travels
  * with the call: the library keeps no mutable state besides the per-thread error string.
  *   envs_per_lane  : lane-major / tiled trajectories and the step path: 0 = auto (16-byte accesses when the batch is large
- *                    enough to fill the chip that way, else one env per lane), 1 / 2 / 4 = forced
+ *                    enough to fill the chip that way, else one env per lane), 1 / 2 / 4 = forced. Ignored (always 1) by
+ *                    excenv_gym_step and by every call that needs the general instantiation (per-env property arrays,
+ *                    gym trajectories, row-major buffers)
  *   env_major_mode : env-major (row-major) buffers — 0: fused LDS time-tile kernel when both layouts are env-major,
  *                    substeps == 1 and the tile fits LDS; 1: never (workspace + transposes, or generic strides)
  *   lds_pad_bytes  : extra dynamic LDS per sim_ahead workgroup (caps resident workgroups per CU; occupancy experiments)

@@ -92,6 +92,13 @@ def test_bench_gpus_2_invoked_directly_starts_its_own_ranks():
     assert d["config"]["global_batch"] == 2 * 65536 and d["config"]["gathered_slice_matches_local"] is True
     assert d["config"]["outputs_finite"] and d["value"] > 0 and d["scaling"] == "weak"
     assert "cpu_baseline" not in d
+    # per-rank visibility: every rank's kernel ms (min, median, max), its own wall time, the end all-gather timed separately
+    assert len(d["per_rank_kernel_ms"]) == 2 and all(len(r) == 3 and 0 < r[0] <= r[1] <= r[2] for r in d["per_rank_kernel_ms"])
+    assert len(d["per_rank_steps_wall_ms"]) == 2 and all(t > 0 for t in d["per_rank_steps_wall_ms"])
+    assert d["gather_ms"] is not None and d["gather_ms"] > 0
+    assert d["value_at_slowest_rank_kernel"] <= d["value_at_median_rank_kernel"] * (1 + 1e-9)
+    r = d["roofline"]
+    assert len(r["kernel_ms_per_step"]) == 3 and r["kernel_ms_spread_pct"] >= 0
 
 
 def test_bench_refuses_world_size_mismatch():
