@@ -131,6 +131,7 @@ class CoreEnvironment(ABC):
         self.last_placement = None           # diagnostics of the most recent placement check (dict) or None
         self._traj_sets = []
         self._placement_best = {}
+        self._placement_replaced = {}
         self._traj_bcast_cache = None
         self._ws_bytes_cache = None
         self._last_out = None
@@ -973,6 +974,7 @@ class CoreEnvironment(ABC):
         """Drop the pooled (dead) trajectory output sets so that their memory returns to torch's allocator."""
         self._traj_sets = []
 
+    _PLACEMENT_REPLACEMENTS = 2
     _PLACEMENT_SPACER_BYTES = 16 << 30  # a rejected block + this much memory stay allocated while the next block is made
 
     def _place_state_block(self, obs_buf, B, rows, OW, S, isz, time_launch):
@@ -1001,7 +1003,11 @@ class CoreEnvironment(ABC):
             if good or k == self._PLACEMENT_TRIES - 1:
                 break
             # the rejected block AND a spacer (hipMalloc outside torch's cache, freed below) stay allocated while the next block
-            # is made, so that it lands >= 16 GiB further on
+            # is made, so that it lands >= 16 GiB further on. Blocks torch holds in its cache (an earlier set's rejected
+            # candidates, for one) would be handed out again at their old addresses whatever the spacer does: they go back to
+            # the driver first (cached, unused memory only; once per search).
+            if k == 0:
+                torch.cuda.empty_cache()
             with _native._on_device(dev):
                 sp = _native.raw_malloc(max(self._PLACEMENT_SPACER_BYTES - S * rows * B * isz, 1 << 20))
             if sp is not None:
@@ -1012,7 +1018,7 @@ class CoreEnvironment(ABC):
                 break
         t_best, best = min(tried, key=lambda tb: tb[0])
         self._placement_best[pkey] = t_best if known is None else min(known, t_best)
-        diag = {"candidate_ms": [round(t, 4) for t, _ in tried], "chosen": [t for t, _ in tried].index(t_best),
+        diag = {"candidate_ms": [round(t, 4) for t, _ in tried], "chosen": [t for t, _ in tried].index(t_best), "chosen_ms": t_best,
                 "best_known_ms_before": known, "spacer_gib": self._PLACEMENT_SPACER_BYTES / 2**30,
                 "what": "trajectory launch of the call timed into (observations, candidate state block); rejected blocks and a "
                         "spacer stay allocated while the next candidate is made"}
@@ -1040,6 +1046,15 @@ class CoreEnvironment(ABC):
         if pooled:
             for k, ts in enumerate(self._traj_sets):
                 if ts.key == key and self._traj_set_is_free(ts, stream):
+                    # a dead set whose placement turned out clearly slower than what a later search found is not worth keeping:
+                    # it is dropped and a new one is placed against the better time (at most _PLACEMENT_REPLACEMENTS times)
+                    best = self._placement_best.get((B, rows, OW, S))
+                    ms = (ts.placement or {}).get("chosen_ms")
+                    if (best is not None and ms is not None and ms > 1.05 * best and (OW + S) * rows * B * isz >= (1 << 30)
+                            and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS and launch is not None):
+                        self._placement_replaced[key] = self._placement_replaced.get(key, 0) + 1
+                        del self._traj_sets[k]
+                        break
                     self._traj_sets.append(self._traj_sets.pop(k))  # most recently used last
                     return ts
             self._traj_sets = [t for t in self._traj_sets if t.key == key][-(self._TRAJ_POOL_SETS - 1):] if self._TRAJ_POOL_SETS > 1 else []
