@@ -531,6 +531,7 @@ class CoreEnvironment(ABC):
         __slots__ = ("n", "i", "leaves", "obs", "out_ptrs", "obs_ptrs", "gym", "gym_ptrs", "phys", "objs", "tens", "rc0",
                      "storages", "use0", "stream", "obs_width")
 
+    _SPLIT_SLOT_POOL_BYTES = 256 << 20
     _storage_use_count = getattr(torch._C, "_storage_Use_Count", None)
     _tensor_use_count = getattr(torch.Tensor, "_use_count", None)
 
@@ -542,14 +543,28 @@ class CoreEnvironment(ABC):
         obs_elems = (B * O + al - 1) // al * al
         rew_elems = Bp if gym else 0
         slot = S * Bp + obs_elems + rew_elems
+        # Large pools: the observations get their own allocation, so that a caller who keeps only observations (a rollout
+        # buffer) does not pin the state leaves of the pool as well. (Placing the two a region apart, DESIGN.md §6.1, was
+        # measured and does nothing for this short streaming kernel.) Small pools stay one allocation (host time).
+        split = n * slot * isz >= self._SPLIT_SLOT_POOL_BYTES
+        if split:
+            slot -= obs_elems
         buf = torch.empty(n * slot, dtype=self.dtype, device=self.device)
         base = buf.data_ptr()
         sl = CoreEnvironment._Slots()
         sl.n, sl.i = n, 0
         sl.leaves = [t.unbind(0) for t in buf.as_strided((n, S, B), (slot, Bp, 1)).unbind(0)]
-        sl.obs = buf.as_strided((n, B, O), (slot, O, 1), S * Bp).unbind(0)
+        obuf = None
+        if split:
+            obuf = torch.empty(n * obs_elems, dtype=self.dtype, device=self.device)
+            obase = obuf.data_ptr()
+            sl.obs = obuf.as_strided((n, B, O), (obs_elems, O, 1)).unbind(0)
+            sl.obs_ptrs = [obase + i * obs_elems * isz for i in range(n)]
+            obs_elems = 0  # the reward column (gym) follows the leaves directly
+        else:
+            sl.obs = buf.as_strided((n, B, O), (slot, O, 1), S * Bp).unbind(0)
+            sl.obs_ptrs = [base + (i * slot + S * Bp) * isz for i in range(n)]
         sl.out_ptrs = [_native.ptr_array([base + (i * slot + j * Bp) * isz for j in range(S)]) for i in range(n)]
-        sl.obs_ptrs = [base + (i * slot + S * Bp) * isz for i in range(n)]
         sl.gym = sl.gym_ptrs = None
         if gym:
             TW = _native.truncated_width(self.ENV_ID, len(self.control_state))
@@ -566,7 +581,7 @@ class CoreEnvironment(ABC):
         sl.phys = [self.PhysicalState(*lv) for lv in sl.leaves]
         sl.tens = [tuple(sl.leaves[i]) + (sl.obs[i],) + (tuple(sl.gym[i]) if gym else ()) for i in range(n)]
         sl.objs = [sl.tens[i] + (sl.phys[i],) for i in range(n)]
-        sl.storages = [buf.untyped_storage()] + ([flags.untyped_storage()] if gym else [])
+        sl.storages = [buf.untyped_storage()] + ([obuf.untyped_storage()] if obuf is not None else []) + ([flags.untyped_storage()] if gym else [])
         sl.rc0 = sl.use0 = sl.stream = None
         return sl
 
