@@ -228,6 +228,63 @@ def calibrate_placement(env, state, actions, args, Kc, B, dtype):
             "same_run_fill_gbs": fill_bytes / t_fill / 1e6, "same_run_pattern_ms": t_pat, "same_run_pattern_rows": rows}
 
 
+def measure_traffic_live(args):
+    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: before this process touches the GPU it runs the
+    workload (tools/traffic_probe.py: a calibration copy of known size + three launches) under `rocprofv3 --pmc` in child
+    processes — FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md §HBM prescribes (FETCH_SIZE counts
+    half of a wide coalesced read stream on gfx950: doubled; WRITE_SIZE exact; both checked on the calibration copy of the same
+    pass). Returns (bytes, description) or (None, reason). Bytes do not depend on where buffers sit, so a sibling process is a
+    faithful measurement of the timed one's traffic. Any failure falls back to the committed passes (profiles/traffic.json)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "already running under a profiler"
+    probe = os.path.join(ROOT, "tools", "traffic_probe.py")
+    hot = "step_kernel" if args.path == "step" else ("sim_ahead_em_kernel" if args.traj_layout == "env_major" and args.action_layout == "env_major" else "sim_ahead_kernel")
+    vals, calib = {}, {}
+    tmp = tempfile.mkdtemp(prefix="excenv_traffic_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, probe,
+                   "--workload", args.workload, "--traj-layout", args.traj_layout, "--action-layout", args.action_layout,
+                   "--path", args.path]
+            if args.batch:
+                cmd += ["--batch", str(args.batch)]
+            if args.chunk:
+                cmd += ["--chunk", str(args.chunk)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            per_kernel = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    per_kernel.setdefault(row.get("Kernel_Name", ""), []).append(float(row.get("Counter_Value", 0) or 0))
+            hk = [v for k, v in per_kernel.items() if hot in k]
+            ck = [v for k, v in per_kernel.items() if "trunc" in k.lower()]
+            if r.returncode != 0 or not hk:
+                return None, f"rocprofv3 --pmc {counter} pass gave no {hot} dispatch (rc {r.returncode})"
+            vals[counter] = float(np.mean(hk[0]))                      # KiB per dispatch
+            calib[counter] = float(np.mean(ck[0])) / float(1 << 20) if ck else None  # x the 1 GiB the copy moves
+    except Exception as e:  # timeouts, missing files, parse errors: never fatal
+        return None, f"live PMC passes failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    desc = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes (separate child processes, before the timed "
+            f"process touched the GPU) over tools/traffic_probe.py; per launch of {hot}: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB "
+            f"(x2, gfx950 correction), WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB; calibration copy of the same passes: FETCH_SIZE "
+            f"reports {calib['FETCH_SIZE']} x the bytes read, WRITE_SIZE {calib['WRITE_SIZE']} x the bytes written")
+    return hbm, desc
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +314,9 @@ def parse_args():
                          "§6) and write it again every step (vmap_sim_ahead(out=...))")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (N = 1 only; "
+                         "~20 s); the committed passes of profiles/traffic.json are replayed instead")
     ap.add_argument("--no-calibration", action="store_true", help="skip the same-run placement calibration after the timed region")
     ap.add_argument("--no-pool", action="store_true", help="every step allocates its outputs (no pooled sets, no placement check)")
     return ap.parse_args()
@@ -296,6 +356,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    live_traffic = (None, "not requested")
+    # the full default line only (quick A/B runs pass --no-cpu-baseline and skip this too); BEFORE anything here touches the GPU
+    if world == 1 and not args.no_live_traffic and not args.no_cpu_baseline:
+        live_traffic = measure_traffic_live(args)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # rehearsal knobs (single-GPU box): EXCENV_BENCH_ONE_GPU=1 puts every rank on GPU 0, EXCENV_BENCH_BACKEND=gloo
     # replaces RCCL (which refuses two ranks on one device). The driver's multi-GPU runs use neither.
@@ -435,15 +499,16 @@ def main():
 
     # HBM traffic per launch from the PMC counters cannot be collected inside this process: it is REPLAYED from the
     # committed rocprofv3 --pmc passes (tools/traffic_probe.py -> profiles/traffic.json) for the same workload key
-    traffic, traffic_source = None, None
+    traffic, traffic_source = live_traffic if live_traffic[0] is not None else (None, None)
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if traffic is None and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             key = f"{args.workload}|B={B}|chunk={Kc}|{args.traj_layout}" + ("|step" if args.path == "step" else "")
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
-                traffic_source = "replayed from profiles/traffic.json (" + tj[key].get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes") + "), not measured in this run"
+                traffic_source = ("replayed from profiles/traffic.json (" + tj[key].get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
+                                  + f"), not measured in this run ({live_traffic[1]})")
         except Exception:
             traffic = None
 
