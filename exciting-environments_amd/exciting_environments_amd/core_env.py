@@ -1012,7 +1012,7 @@ class CoreEnvironment(ABC):
             # enough when this block matches the best placement an earlier set of this shape found, or when two placements
             # have been seen and the better one is clearly (7 %) faster than the other: the two levels have shown themselves
             if known is not None:
-                good = t <= 1.03 * known
+                good = t <= 1.02 * known
             else:
                 good = len(times) >= 2 and min(times) <= self._PLACEMENT_ACCEPT * max(times)
             if good or k == self._PLACEMENT_TRIES - 1:
@@ -1065,7 +1065,7 @@ class CoreEnvironment(ABC):
                     # it is dropped and a new one is placed against the better time (at most _PLACEMENT_REPLACEMENTS times)
                     best = self._placement_best.get((B, rows, OW, S))
                     ms = (ts.placement or {}).get("chosen_ms")
-                    if (best is not None and ms is not None and ms > 1.05 * best and (OW + S) * rows * B * isz >= (1 << 30)
+                    if (best is not None and ms is not None and ms > 1.03 * best and (OW + S) * rows * B * isz >= (1 << 30)
                             and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS and launch is not None):
                         self._placement_replaced[key] = self._placement_replaced.get(key, 0) + 1
                         del self._traj_sets[k]
@@ -1084,13 +1084,14 @@ class CoreEnvironment(ABC):
         if want_states:
             def time_launch(block):
                 ptrs = _native.ptr_array([block.data_ptr() + j * rows * B * isz for j in range(S)])
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-                launch(ts.obs_ptr, ptrs, ts.last_ptrs)  # warm
-                ev[0].record()
-                launch(ts.obs_ptr, ptrs, ts.last_ptrs)
-                ev[1].record()
-                ev[1].synchronize()
-                return float(ev[0].elapsed_time(ev[1]))
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                launch(ts.obs_ptr, ptrs, ts.last_ptrs)  # warm (clocks, TLB)
+                for e in ev[:-1]:  # three timed launches, the fastest counts: the first ones of a process run a few % slow
+                    e.record()
+                    launch(ts.obs_ptr, ptrs, ts.last_ptrs)
+                ev[-1].record()
+                ev[-1].synchronize()
+                return min(float(a.elapsed_time(b)) for a, b in zip(ev[:-1], ev[1:]))
 
             ts.st_buf, ts.placement = self._place_state_block(ts.obs_buf, B, rows, OW, S, isz, time_launch if launch is not None else None)
             self.last_placement = ts.placement
