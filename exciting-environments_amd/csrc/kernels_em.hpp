@@ -43,6 +43,10 @@ static_assert((EXCENV_EM_TK & (EXCENV_EM_TK - 1)) == 0 && EXCENV_EM_TK >= 2 && E
 static_assert(EM_LANES == 64, "the fused env-major kernel relies on a single wave64 per workgroup");
 __device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
 
+#ifndef EXCENV_EM_DEBUG
+#define EXCENV_EM_DEBUG 0  // experiments only (results are wrong): 1 skip the observation stores, 2 skip the flush, 4 skip the action-line walk
+#endif
+
 template <typename T> __host__ __device__ constexpr int em_tk() { return sizeof(T) == 4 ? EXCENV_EM_TK : EXCENV_EM_TK / 2; }
 
 // LDS elements per wave: the per-lane action line (128 bytes + one 16-byte pad), the ring of saved states, one round of
@@ -186,7 +190,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
           const unsigned ro = row_off[row];
           T v[VW];
           load_v<T, VW>(stage + p * VW, v);
-          if (ro != 0xffffffffu) store_stream<T, VW>(wg_obs + ro * (unsigned)O + (unsigned)(piece * VW), v);
+          if (!(EXCENV_EM_DEBUG & 1) && ro != 0xffffffffu) store_stream<T, VW>(wg_obs + ro * (unsigned)O + (unsigned)(piece * VW), v);
         }
       } else {
         T fs[S];
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
     // only has to outlast the stores of the PREVIOUS step's flush, not stores issued a few instructions ago.
     const int64_t k1 = (n + 1 < ka.K) ? n + 1 : ka.K - 1;
     const int64_t r1 = row0 + k1 * A;
-    if (n < N && (r1 & ~(int64_t)(WPL - 1)) != cur_line) {
+    if (!(EXCENV_EM_DEBUG & 4) && n < N && (r1 & ~(int64_t)(WPL - 1)) != cur_line) {
       park_line(park_from);
       cur_line += WPL;
       load_line(cur_line + WPL, load_into);
@@ -278,6 +282,7 @@ __global__ void __launch_bounds__(EM_LANES) sim_ahead_em_kernel(const SimArgs<T,
     // environments whose window ends with step n (or with the trajectory)
     const bool due = active && ((((my_ph + (unsigned)slot + 1u) % TK) == 0u) || n == N);
     unsigned long long mask = __ballot(due);
+    if (EXCENV_EM_DEBUG & 2) mask = 0;
     while (mask) flush_round(mask, n);
     if (n < N) {
       T a_nxt[A];
