@@ -964,25 +964,26 @@ class CoreEnvironment(ABC):
         return observations, st_views, last, N
 
     # -- large trajectory outputs ----------------------------------------------------------------------------------------
-    # Where the driver places tens of GB of trajectory buffers in physical memory moves the trajectory kernel by 15-19 %
-    # (tools/microbench/placement_pattern.hip): device memory consists of large physical regions, and write traffic
-    # that falls into ONE region at a time — observations and state leaves allocated back to back by a fresh process — runs
-    # at ~5.0 TB/s where the same kernel over buffers in two regions runs at ~5.9 TB/s; a plain sequential fill shows the same
-    # two levels, so this is the platform, not the kernel. Virtual addresses say nothing about the region, so a new set of
-    # output buffers is CHECKED: the library's no-arithmetic access pattern (excenv_stream_pattern) is timed once with every
-    # stream inside the observation buffer (one region at any time: the slow level, by construction) and once over the
-    # candidate (observations + a state-leaf block); a candidate that is not clearly faster is kept allocated as a spacer while
-    # another block is tried (at most _PLACEMENT_TRIES, then the best one seen is taken). Cost: a few launches of the size of one
-    # trajectory call, once per set. Sets are then pooled: a dead set (same test as the vmap_step slots: no Python reference,
-    # no C++ holder, no foreign view, same stream) is written again instead of allocating a new one, so a chained run
-    # (`obs, states, last = env.vmap_sim_ahead(last, actions, ...)`) alternates between two checked sets.
+    # Where the driver places tens of GB of trajectory buffers in physical memory moves the trajectory kernel by 15-20 %
+    # (profiles/r03_placement_regions.md): device memory behaves as a few large physical regions, and write
+    # traffic that falls into ONE region at a time — observations and state leaves allocated back to back by a fresh process —
+    # runs at ~5.0 TB/s where the same kernel over buffers in two regions runs at ~5.9 TB/s; a plain sequential fill shows the
+    # same two levels, so this is the platform, not the kernel. Virtual addresses say nothing about the region, so a new set of
+    # output buffers is PLACED BY MEASUREMENT: the trajectory launch of the very call that needs the set is timed into
+    # (observations, candidate state block); while another candidate is made, the rejected block and a 16 GiB spacer (hipMalloc
+    # outside torch's cache) stay allocated, so that it lands a region further on. The first set of a shape tries at least two
+    # placements and stops when one is clearly (7 %) faster than another (both levels have shown themselves); later sets stop at
+    # the first block that matches the best time known; at most _PLACEMENT_TRIES candidates, the fastest is kept, everything else
+    # is freed. Cost: ~4 launches per candidate, once per set. Sets are then pooled: a dead set (same test as the vmap_step
+    # slots: no Python reference, no C++ holder, no foreign view, same stream) is written again instead of allocating a new
+    # one, so a chained run (`obs, states, last = env.vmap_sim_ahead(last, actions, ...)`) alternates between two placed sets.
     class _TrajSet:
         __slots__ = ("key", "obs_buf", "st_buf", "lbuf", "observations", "st_views", "last", "obs_ptr", "traj_ptrs", "last_ptrs",
                      "tens", "storages", "rc0", "use0", "stream", "placement")
 
     _PLACED_TRAJ_BYTES = 1 << 30  # output sets at least this large go through the placement check
     _PLACEMENT_TRIES = 4
-    _PLACEMENT_ACCEPT = 0.93      # candidate time / one-region time at or below this: the set spans regions
+    _PLACEMENT_ACCEPT = 0.93      # fastest / slowest candidate at or below this: the two levels have both been seen
     _TRAJ_POOL_SETS = 2
 
     def release_trajectory_buffers(self):
@@ -1005,32 +1006,33 @@ class CoreEnvironment(ABC):
         pkey = (B, rows, OW, S)
         known = self._placement_best.get(pkey)
         tried, spacers = [], []
-        for k in range(self._PLACEMENT_TRIES):
-            t = time_launch(block)
-            tried.append((t, block))
-            times = [x for x, _ in tried]
-            # enough when this block matches the best placement an earlier set of this shape found, or when two placements
-            # have been seen and the better one is clearly (7 %) faster than the other: the two levels have shown themselves
-            if known is not None:
-                good = t <= 1.02 * known
-            else:
-                good = len(times) >= 2 and min(times) <= self._PLACEMENT_ACCEPT * max(times)
-            if good or k == self._PLACEMENT_TRIES - 1:
-                break
-            # the rejected block AND a spacer (hipMalloc outside torch's cache, freed below) stay allocated while the next block
-            # is made, so that it lands >= 16 GiB further on. Blocks torch holds in its cache (an earlier set's rejected
-            # candidates, for one) would be handed out again at their old addresses whatever the spacer does: they go back to
-            # the driver first (cached, unused memory only; once per search).
-            if k == 0:
-                torch.cuda.empty_cache()
-            with _native._on_device(dev):
-                sp = _native.raw_malloc(max(self._PLACEMENT_SPACER_BYTES - S * rows * B * isz, 1 << 20))
-            if sp is not None:
-                spacers.append(sp)
-            try:
-                block = torch.empty((S, rows, B), dtype=dt, device=dev)
-            except torch.OutOfMemoryError:
-                break
+        try:
+            for k in range(self._PLACEMENT_TRIES):
+                t = time_launch(block)
+                tried.append((t, block))
+                times = [x for x, _ in tried]
+                if known is not None:
+                    good = t <= 1.02 * known
+                else:
+                    good = len(times) >= 2 and min(times) <= self._PLACEMENT_ACCEPT * max(times)
+                if good or k == self._PLACEMENT_TRIES - 1:
+                    break
+                # Blocks torch holds in its cache (an earlier set's rejected candidates, for one) would be handed out again at
+                # their old addresses whatever the spacer does: they go back to the driver first (cached, unused memory only;
+                # once per search).
+                if k == 0:
+                    torch.cuda.empty_cache()
+                with _native._on_device(dev):
+                    sp = _native.raw_malloc(max(self._PLACEMENT_SPACER_BYTES - S * rows * B * isz, 1 << 20))
+                if sp is not None:
+                    spacers.append(sp)
+                try:
+                    block = torch.empty((S, rows, B), dtype=dt, device=dev)
+                except torch.OutOfMemoryError:
+                    break
+        finally:
+            for sp in spacers:
+                _native.raw_free(sp)
         t_best, best = min(tried, key=lambda tb: tb[0])
         self._placement_best[pkey] = t_best if known is None else min(known, t_best)
         diag = {"candidate_ms": [round(t, 4) for t, _ in tried], "chosen": [t for t, _ in tried].index(t_best), "chosen_ms": t_best,
@@ -1038,8 +1040,6 @@ class CoreEnvironment(ABC):
                 "what": "trajectory launch of the call timed into (observations, candidate state block); rejected blocks and a "
                         "spacer stay allocated while the next candidate is made"}
         del tried, block
-        for sp in spacers:
-            _native.raw_free(sp)
         return best, diag
 
     def _traj_set_is_free(self, ts, stream) -> bool:
