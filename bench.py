@@ -260,7 +260,21 @@ def measure_traffic_live(args):
             if args.chunk:
                 cmd += ["--chunk", str(args.chunk)]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
+            # own process group, killed as a whole on a timeout (rocprofv3 starts the probe as its child)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                    start_new_session=True)
+            try:
+                proc.communicate(timeout=120)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.communicate()
+                return None, f"rocprofv3 --pmc {counter} pass timed out"
+            r = proc
             per_kernel = {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
