@@ -160,3 +160,39 @@ def test_stream_pattern_rejects_bad_arguments():
     p_odd = (ctypes.c_void_p * 1)(buf.data_ptr() + 4)
     assert lib.excenv_stream_pattern(0, None, None, 1, p_odd, rs, 4096, 1, 1, None) == -1
     torch.cuda.synchronize()
+
+
+def test_placement_search_logic_with_scripted_timings():
+    """The decision rules of the placement search, with the launch timing replaced by a script: the first set of a shape tries
+    at least two candidates and stops at a 7 % contrast; a later set stops at the first candidate within 2 % of the best time
+    known; without contrast all tries are used and the fastest wins; rejected blocks are released."""
+    env, _ = _env("pmsm", B=1024)
+    env._PLACEMENT_SPACER_BYTES = 1 << 20
+    B, rows, OW, S, isz = 1024, 9, 8, 7, 4
+
+    def run(times):
+        seen, it = [], iter(times)
+
+        def fake(block):
+            seen.append(block.data_ptr())
+            return next(it)
+
+        obs_buf = torch.empty((rows, OW, B), dtype=torch.float32, device=env.device)
+        block, diag = env._place_state_block(obs_buf, B, rows, OW, S, isz, fake)
+        return block, diag, seen
+
+    env._placement_best.clear()
+    block, diag, seen = run([5.4, 4.9, 9.9, 9.9])          # contrast after two candidates: stop, keep the second
+    assert diag["candidate_ms"] == [5.4, 4.9] and diag["chosen"] == 1 and block.data_ptr() == seen[1]
+    assert env._placement_best[(B, rows, OW, S)] == 4.9
+    block, diag, seen = run([4.95, 9.9])                   # a later set: within 2 % of the best known -> first candidate
+    assert diag["candidate_ms"] == [4.95] and diag["best_known_ms_before"] == 4.9
+    block, diag, seen = run([5.3, 5.35, 5.1, 5.2])         # never matches 4.9: all four tried, the fastest kept
+    assert len(diag["candidate_ms"]) == 4 and diag["chosen"] == 2 and block.data_ptr() == seen[2]
+    assert len(set(seen)) == 4                             # four distinct blocks were alive at the same time
+    env._placement_best.clear()
+    block, diag, seen = run([5.0, 5.05, 5.02, 4.98])       # first set, no contrast: all tries, fastest kept
+    assert len(diag["candidate_ms"]) == 4 and diag["chosen"] == 3
+    env.trajectory_placement = "off"
+    block, diag, seen = run([1.0])
+    assert diag is None and seen == []
