@@ -329,9 +329,13 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
     return;                                                                                                                     \
   } while (0)
   if (general) EXCENV_SIM_LAUNCH(true, 1, -1);
-  constexpr int VMAX = 16 / (int)sizeof(T);
-  if (ka.straj[0] == nullptr)  // observations only: instantiated for the widest lanes (launch_sim routes the rest to `general`)
-    EXCENV_SIM_LAUNCH(false, VMAX, 0);
+  if (ka.straj[0] == nullptr) {  // observations only: its own instantiations (no state stores between the action loads and their waits)
+    if constexpr (sizeof(T) == 4) {
+      if (V == 4) EXCENV_SIM_LAUNCH(false, 4, 0);
+    }
+    if (V == 2) EXCENV_SIM_LAUNCH(false, 2, 0);
+    EXCENV_SIM_LAUNCH(false, 1, 0);
+  }
   if constexpr (sizeof(T) == 4) {
     if (V == 4) EXCENV_SIM_LAUNCH(false, 4, 1);
   }
@@ -488,10 +492,6 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     } else {
       V = VT;
     }
-  }
-  if (!general && ka.straj[0] == nullptr && V != VMAX) {  // observations only exists for the widest lanes and in the general kernel
-    general = true;
-    V = 1;
   }
   {  // element offset of workgroup w's first env in each stream
     const int64_t wg_envs = (int64_t)BLOCK * V;
