@@ -58,7 +58,7 @@ static int check_opts(const char* fn, const excenv_launch_opts_t*& o) {
   if (!o) o = &kDefaultOpts;
   const int v = o->envs_per_lane;
   if (!(v == 0 || v == 1 || v == 2 || v == 4)) { set_error("%s: opts.envs_per_lane must be 0, 1, 2 or 4 (got %d)", fn, v); return EXCENV_EINVAL; }
-  if (o->env_major_mode != 0 && o->env_major_mode != 1) { set_error("%s: opts.env_major_mode must be 0 or 1", fn); return EXCENV_EINVAL; }
+  if (o->env_major_mode < 0 || o->env_major_mode > 3) { set_error("%s: opts.env_major_mode must be 0, 1, 2 or 3", fn); return EXCENV_EINVAL; }
   if (o->lds_pad_bytes < 0 || o->lds_pad_bytes > 150 * 1024) { set_error("%s: opts.lds_pad_bytes out of range", fn); return EXCENV_EINVAL; }
   if (o->reserved != 0) { set_error("%s: opts.reserved must be 0", fn); return EXCENV_EINVAL; }
   return EXCENV_OK;
@@ -211,7 +211,7 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
                                                         state_traj != nullptr);
   const bool via_ws = !fused_em && !gym && workspace && need > 0 && workspace_bytes >= need && B > 0 &&
                       (action_layout == EXCENV_LAYOUT_ENV_MAJOR || traj_layout == EXCENV_LAYOUT_ENV_MAJOR);
-  const int em = fused_em ? 2 : 1;
+  const int em = !fused_em ? 1 : (opts->env_major_mode == 2 ? 3 : (opts->env_major_mode == 3 ? 4 : 2));
   if (!via_ws) {
     SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, actions, action_layout,
                obs_traj, state_traj, traj_layout, last_state, semantics, opts->envs_per_lane, opts->lds_pad_bytes, em, gym,

@@ -1,0 +1,286 @@
+// Fused env-major (reference row-major) trajectory kernel, register-ring form (round 3): actions [B][K][A] in, observations
+// [B][N+1][O] and state leaves [B][N+1] out, no transposition pass — and every store instruction writes WHOLE 128-byte lines.
+//
+// Why a second form. The LDS-ring kernel (kernels_em.hpp) keeps TK = 8 saved states per environment in LDS (more does not fit
+// next to enough waves) and so writes the state leaves as 32-byte runs; what that costs is set by the memory system, not by
+// the kernel (tools/em_placement.py: the same launch takes 9.3 ... 13.1 ms depending only on where the leaves lie). Here a lane
+// keeps a whole window of W = 128 / sizeof(T) saved states of ITS environment in registers (one native W-element vector per
+// state leaf, written with a wave-uniform dynamic index: s_set_gpr_idx_on + v_mov), so a window of a leaf is one 128-byte line
+// per environment.
+//   * UNIFORM PHASE. A line of env e's leaf row starts where (e * (N + 1) + n) % W == 0. Lanes of a wave take environments P
+//     apart, P = the period of that phase in e (a power of two <= W; the host computes it together with the same period of the
+//     action rows' line phase and passes the larger one): all 64 environments of a wave cross their line boundaries at the same
+//     steps, every ring index and every branch of the flush is wave-uniform.
+//   * FLUSH, once per W steps (plus head and tail): per leaf the 8 sixteen-byte pieces of a lane's line go through an 8 KB LDS
+//     buffer in which each group of 8 lanes transposes its 8 x 8 pieces, so that a store instruction's 8 adjacent lanes write
+//     the 8 pieces of ONE environment's line: 64 lanes x 16 bytes = 8 whole lines per instruction. The observation rows of the
+//     window (O whole lines per environment) are evaluated from the ring at flush time (same device function on the same saved
+//     state as every other kernel: same bits) and leave the same way. Head / tail windows use the same code with a slot range;
+//     pieces cut by the range fall back to element stores.
+//   * ACTIONS. As in the LDS-ring kernel every 128-byte line is fetched once, a whole line (W / A steps) ahead, into registers
+//     and parked in a per-lane LDS slot when the walk crosses into it; with the uniform phase the crossing is wave-uniform.
+// One wave per workgroup (LDS accesses of a wave execute in order: compiler fences only), one wave per SIMD (registers).
+#pragma once
+#include "kernels_em.hpp"
+
+namespace excenv {
+
+template <typename T, int W> struct EmrVec { typedef T type __attribute__((ext_vector_type(W))); };
+
+// Steps per window. Two waves must share a SIMD (one wave alone leaves the VALU half idle: 9.9 ms for the headline launch with
+// 128-byte windows at one wave per SIMD, 7.7 ms with 64-byte windows at two), so a lane has 256 registers and the windows of
+// ALL state leaves must fit next to the integration's own: 128-byte runs (whole lines) for models with up to three state
+// leaves, 64-byte runs (half lines, written 4 lanes x 16 bytes) for the others. PMSM in fp64 does not fit either way (7 leaves
+// x 8 doubles + a double-precision integration: > 100 registers spilled) and stays on the LDS-ring kernel.
+template <class M, typename T> constexpr int emr_rows() { return (M::S > 3 ? 64 : 128) / (int)sizeof(T); }
+template <class M, typename T> constexpr bool emr_supported() { return !M::HAS_LUT && !(M::S > 4 && sizeof(T) == 8); }
+
+// LDS bytes per wave: the transposition buffer (64 lanes x one run) and the action line slots (64 x 128 bytes)
+template <class M, typename T> constexpr size_t emr_lds_bytes() { return (size_t)EM_LANES * (emr_rows<M, T>() * sizeof(T) + 128); }
+
+#ifndef EXCENV_EMR_DEBUG
+#define EXCENV_EMR_DEBUG 0  // experiments only (results are wrong): 1 never walk to the next action line, 2 no flush, 4 flush without global stores
+#endif
+#ifndef EXCENV_EMR_NT
+#define EXCENV_EMR_NT 1  // whole-line stores of the flush are non-temporal
+#endif
+
+// ka.a_wg carries P (environments between consecutive lanes of a wave) on this path.
+template <class M, typename T, int SOLVER, bool AHEAD>
+__global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2, 2))) sim_ahead_emr_kernel(const SimArgs<T, M> ka) {
+  constexpr int S = M::S, A = M::A, O = M::O;
+  constexpr int VW = 16 / (int)sizeof(T);   // elements per 16-byte piece
+  constexpr int W = emr_rows<M, T>();       // steps per window == elements per run of a state leaf
+  constexpr int NPC = W / VW;               // 16-byte pieces per run (4 or 8); the lanes of a wave transpose in groups of NPC
+  constexpr int WL = 128 / (int)sizeof(T);  // elements per 128-byte line of the action array
+  constexpr int NPL = 8;                    // pieces per action line
+  constexpr int RPO = W / O;                // saved rows per observation run
+  static_assert(W % O == 0, "an observation row must divide a run");
+  static_assert(WL % A == 0 && VW % A == 0, "an action row must not straddle a 16-byte piece");
+  using Vec = typename EmrVec<T, W>::type;
+  extern __shared__ __align__(16) unsigned char excenv_emr_smem[];
+  T* const xp = reinterpret_cast<T*>(excenv_emr_smem);  // [64 lanes][NPC pieces], piece p of lane l at position p ^ (l % NPC)
+  T* const slot_a = xp + EM_LANES * W;                  // [8 pieces][64 lanes]: the action line each lane is in
+
+  const int lane = threadIdx.x;
+  const int P = (int)ka.a_wg;
+  const int64_t wv = blockIdx.x;
+  const int r = (int)(wv % P);
+  const int64_t env0 = (wv / P) * ((int64_t)EM_LANES * P) + r;  // lane 0's environment
+  const int64_t env = env0 + (int64_t)P * lane;
+  const bool active = env < ka.B;
+  Ctx<T, M> c;
+  load_ctx<false>(c, ka.kp, 0, ka.dt, ka.env_tau, ka.adv_coef);
+  c.lin_stop = ka.lin_stop;
+  c.lin_div = T(ka.K - 1);
+  c.lin_last = ka.K - 1;
+  T st[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) st[j] = active ? ka.state_in[j][env] : T(0);
+  AheadAux<T> aux;
+  if constexpr (AHEAD && M::IS_PMSM) {
+    aux.eps0 = st[2];
+    aux.prev_clip[0] = st[0];
+    aux.prev_clip[1] = st[1];
+  }
+  const bool deadtime_on = M::IS_PMSM ? (c.P[M::P - 1] > T(0)) : false;
+  const bool with_states = ka.straj[0] != nullptr;
+
+  const int64_t N = ka.K;  // substeps == 1 on this path (host); K >= 1 (host)
+  const int64_t rowlen = N + 1;
+  // wave-uniform window phase: slot of row n in the ring = (ph + n) % W (leaf and observation bases are 128-byte aligned, host)
+  const int ph = (int)(((int64_t)r * (rowlen % W)) % W);
+
+  // ---- actions: line store with a wave-uniform phase ----
+  const int64_t off128 = (int64_t)(((uintptr_t)ka.actions & 127u) / sizeof(T));
+  const int64_t n_act = ka.B * ka.K * A;
+  const int64_t row0 = off128 + (active ? env : env0) * ka.K * A;  // this lane's action row 0 (element offset from the boundary)
+  const int pha = (int)((off128 + (int64_t)r * ((ka.K * A) % WL)) % WL);  // == row0 % WL for every lane
+  const int64_t line0 = row0 - pha;                                  // this lane's first line
+  auto load_line = [&](int64_t li, T (&dst)[WL]) {  // line number li of the lane's walk into registers, no wait
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      int64_t p = line0 + li * WL + VW * i - off128;  // element index into ka.actions
+      p = (p < 0) ? 0 : p;
+      p = (p + VW > n_act) ? n_act - VW : p;
+      T v[VW];
+      load_v<T, VW>(ka.actions + p, v);
+#pragma unroll
+      for (int h = 0; h < VW; ++h) dst[i * VW + h] = v[h];
+    }
+  };
+  auto park_line = [&](const T (&src)[WL]) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      T v[VW];
+#pragma unroll
+      for (int h = 0; h < VW; ++h) v[h] = src[i * VW + h];
+      store_v<T, VW>(slot_a + (i * EM_LANES + lane) * VW, v);
+    }
+  };
+  auto read_row = [&](int idx, T (&a)[A]) {  // row at element idx of the parked line
+    load_row<T, A>(slot_a + ((idx / VW) * EM_LANES + lane) * VW + idx % VW, a);
+  };
+
+  if (env0 >= ka.B) return;  // no barrier is ever used: a wave without environments may leave
+  Vec ring[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) ring[j] = (Vec)(T(0));
+  T* const obs_base = ka.obs;
+
+  // ---- flush the ring slots [s_lo, s_hi]; slot 0 is row n_slot0 of every environment of the wave ----
+  const int pi = lane % NPC;  // the piece this lane stores
+  const int g8 = lane - pi;   // first lane of its group of NPC
+  const bool full_wave = env0 + (int64_t)P * (EM_LANES - 1) < ka.B;  // every lane has an environment (wave-uniform)
+  const int64_t env_g8 = env0 + (int64_t)P * g8;                      // environment of the group's first lane
+  // One line per environment out of the transposition buffer. `line(q)`: pointer to this lane's piece of the line of the
+  // group's q-th environment; `slot_of(h)`: ring slot that element h of this lane's piece belongs to.
+  auto put_pieces = [&](const T (&src)[W]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      T v[VW];
+#pragma unroll
+      for (int h = 0; h < VW; ++h) v[h] = src[i * VW + h];
+      store_v<T, VW>(xp + (lane * NPC + (i ^ pi)) * VW, v);
+    }
+    wave_sync();
+  };
+  auto emit_lines = [&](T* p0, int64_t q_stride, bool fast, int s_lo, int s_hi, auto&& slot_of) __attribute__((always_inline)) {
+    if (fast) {  // whole window, whole wave: eight reads, eight whole-line stores, no lane-dependent control flow
+      T v[NPC][VW];
+#pragma unroll
+      for (int q = 0; q < NPC; ++q) load_v<T, VW>(xp + ((g8 + q) * NPC + (pi ^ q)) * VW, v[q]);
+#pragma unroll
+      for (int q = 0; q < NPC; ++q) {
+#if EXCENV_EMR_DEBUG & 4
+        asm volatile("" ::"v"(v[q][0]), "v"(v[q][VW - 1]), "v"(p0 + q * q_stride));
+#elif EXCENV_EMR_NT
+        store_stream<T, VW>(p0 + q * q_stride, v[q]);
+#else
+        store_v<T, VW>(p0 + q * q_stride, v[q]);
+#endif
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NPC; ++q) {
+        T v[VW];
+        load_v<T, VW>(xp + ((g8 + q) * NPC + (pi ^ q)) * VW, v);
+        T* const p = p0 + q * q_stride;
+        if (env_g8 + (int64_t)P * q < ka.B) {
+          bool ok[VW], all = true, any = false;
+#pragma unroll
+          for (int h = 0; h < VW; ++h) {
+            const int sl = slot_of(h);
+            ok[h] = s_lo <= sl && sl <= s_hi;
+            all &= ok[h];
+            any |= ok[h];
+          }
+          if (all) {
+            store_v<T, VW>(p, v);
+          } else if (any) {
+#pragma unroll
+            for (int h = 0; h < VW; ++h)
+              if (ok[h]) p[h] = v[h];
+          }
+        }
+      }
+    }
+    wave_sync();
+  };
+  auto flush = [&](int s_lo, int s_hi, int64_t n_slot0) __attribute__((always_inline)) {
+    const bool fast = full_wave && (s_lo == 0) && (s_hi == W - 1);
+    const int64_t row_g8 = env_g8 * rowlen + n_slot0;  // (environment, slot 0) of the group's first lane, in rows
+    if (with_states) {
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        T ln[W];
+#pragma unroll
+        for (int h = 0; h < W; ++h) ln[h] = ring[j][h];
+        put_pieces(ln);
+        emit_lines(ka.straj[j] + row_g8 + pi * VW, (int64_t)P * rowlen, fast, s_lo, s_hi, [&](int h) { return pi * VW + h; });
+      }
+    }
+    // observation lines: line l of the window holds rows [l * RPO, (l + 1) * RPO)
+#pragma unroll 1
+    for (int l = 0; l < O; ++l) {
+      if ((l + 1) * RPO - 1 < s_lo || l * RPO > s_hi) continue;  // wave-uniform
+      T pk[W];
+#pragma unroll
+      for (int t = 0; t < RPO; ++t) {
+        T fs[S], ob[O];
+#pragma unroll
+        for (int j = 0; j < S; ++j) fs[j] = ring[j][l * RPO + t];
+        M::observe(fs, c, ob);
+#pragma unroll
+        for (int q = 0; q < O; ++q) pk[t * O + q] = ob[q];
+      }
+      put_pieces(pk);
+      // element (row s, column o) of the window sits at ((env * rowlen + n_slot0 + s) * O + o); line l starts at s = l * RPO
+      emit_lines(obs_base + row_g8 * O + (int64_t)l * W + pi * VW, (int64_t)P * rowlen * O, fast, s_lo, s_hi,
+                 [&](int h) { return l * RPO + (pi * VW + h) / O; });
+    }
+  };
+
+  T lineR[WL];  // the prefetched next line
+  {
+    T first[WL];
+    load_line(0, first);
+    park_line(first);
+  }
+  load_line(1, lineR);
+  int64_t lidx = 0;  // number of the line in the slot
+  T a_cur[A], sv[S];
+  wave_sync();
+  read_row(pha, a_cur);
+
+  for (int64_t n = 0; n <= N; ++n) {
+    const int slot = (int)((ph + n) % W);
+    // Row n + 1 of the actions (clamped) is what this step still needs (row n is in a_cur). When it starts the next line, that
+    // line moves from the registers into the slot and the one after it is requested (wave-uniform).
+    const int64_t k1 = (n + 1 < ka.K) ? n + 1 : ka.K - 1;
+    const int64_t pos1 = pha + k1 * A;
+    if (!(EXCENV_EMR_DEBUG & 1) && n < N && pos1 / WL != lidx) {
+      park_line(lineR);
+      ++lidx;
+      load_line(lidx + 1, lineR);
+      wave_sync();
+    }
+    T a_nxt[A];  // requested here, used by the integration below: the save in between covers the LDS latency
+    read_row((int)(pos1 % WL), a_nxt);
+#pragma unroll
+    for (int j = 0; j < S; ++j) sv[j] = st[j];
+    if constexpr (AHEAD) {
+      M::post(sv, c);
+      if constexpr (M::IS_PMSM) {
+        if (deadtime_on) {
+          sv[0] = aux.prev_clip[0];  // row 0: still the initial buffer
+          sv[1] = aux.prev_clip[1];
+        } else {
+          sv[0] = T(0);
+          sv[1] = T(0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) ring[j][slot] = sv[j];
+    if (!(EXCENV_EMR_DEBUG & 2) && (slot == W - 1 || n == N)) {
+      const int back = (int)((n < slot) ? n : slot);  // rows of the window before row n
+      flush(slot - back, slot, n - slot);
+    }
+    if (n < N) {
+      if constexpr (AHEAD) {
+        env_advance_raw<M, SOLVER>(st, a_cur, a_nxt, n, k1, c, aux);
+      } else {
+        env_step<M, SOLVER>(st, a_cur, c);
+      }
+#pragma unroll
+      for (int q = 0; q < A; ++q) a_cur[q] = a_nxt[q];
+    }
+  }
+  if (active) {  // row N was saved last: publish last_state from registers
+#pragma unroll
+    for (int j = 0; j < S; ++j) ka.last_state[j][env] = sv[j];
+  }
+}
+
+}  // namespace excenv

@@ -4,7 +4,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
-#include "kernels_em.hpp"
+#include <cstdlib>
+#include "kernels_emr.hpp"
 #include "refgen.hpp"
 
 namespace excenv {
@@ -48,13 +49,20 @@ struct SimCall {
   int semantics;
   int vec_pref;  // 0 auto, else forced envs-per-lane (1, 2, 4)
   int lds_pad;   // dynamic LDS bytes per workgroup (occupancy shaping experiments; 0 = none)
-  int em_mode;   // env-major buffers: 0 = fused LDS time-tile kernel when eligible, 1 = never (generic strides / workspace)
+  int em_mode;   // env-major buffers: 1 = not fused (generic strides / workspace); fused: 2 = pick the kernel, 3 = LDS-ring kernel,
+                 // 4 = register-ring kernel whenever its preconditions hold (no batch-size heuristic)
   const excenv_traj_gym_t* gym;  // optional reward / terminated / truncated trajectories
   hipStream_t stream;
 };
 
 // The fused env-major kernel applies when both layouts are env-major, substeps == 1, the caller did not opt out, no gym
 // trajectories are requested and the time tile fits LDS. Decided once per call (excenv_api.hip) and handed to launch_sim.
+// EXCENV_EM_RING=0 in the environment keeps the LDS-ring kernel (A/B measurements)
+static inline bool emr_enabled() {
+  static const int on = [] { const char* e = std::getenv("EXCENV_EM_RING"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
+
 static inline bool em_fused_eligible(int em_mode, int action_layout, int traj_layout, int32_t substeps, bool with_gym,
                                      int A, int S, int O, size_t elem) {
   return em_mode != 1 && action_layout == EXCENV_LAYOUT_ENV_MAJOR && traj_layout == EXCENV_LAYOUT_ENV_MAJOR &&
@@ -436,12 +444,42 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     }
   }
 
-  if (sc.em_mode == 2 && !em_fused_eligible(0, sc.action_layout, sc.traj_layout, sc.substeps, sc.gym != nullptr, M::A, M::S, M::O,
-                                            sizeof(T))) {  // em_mode 2 is produced by excenv_sim_ahead_ws only; never trust it blindly
+  if (sc.em_mode >= 2 && !em_fused_eligible(0, sc.action_layout, sc.traj_layout, sc.substeps, sc.gym != nullptr, M::A, M::S, M::O,
+                                            sizeof(T))) {  // em_mode >= 2 is produced by excenv_sim_ahead_ws only; never trust it blindly
     set_error("excenv_sim_ahead: internal error: fused env-major kernel selected for an ineligible call");
     return EXCENV_EINVAL;
   }
-  if (sc.em_mode == 2) {  // decided by the caller (em_fused_eligible): fused env-major kernel, one wave per 64 envs,
+  if ((sc.em_mode == 2 || sc.em_mode == 4) && !general && emr_supported<M, T>() && emr_enabled()) {
+    // register-ring form (kernels_emr.hpp): whole-line stores. Needs 128-byte aligned trajectory arrays and enough environments
+    // to fill waves whose lanes are P environments apart.
+    constexpr int64_t W = emr_rows<M, T>(), WL = 128 / (int64_t)sizeof(T);
+    auto period = [](int64_t x, int64_t m) { int64_t g = m, y = x % m; while (y) { const int64_t t = g % y; g = y; y = t; } return m / g; };
+    const int64_t Ps = period(sc.K + 1, W), Pa = period(sc.K * M::A, WL);
+    const int64_t P = Ps > Pa ? Ps : Pa;
+    bool ok = ((uintptr_t)ka.obs % 128) == 0 && (sc.em_mode == 4 || sc.B >= 16 * EM_LANES * P);
+    for (int j = 0; j < M::S; ++j) ok &= ka.straj[j] == nullptr || ((uintptr_t)ka.straj[j] % 128) == 0;
+    if (ok) {
+      SimArgs<T, M> kr = ka;
+      kr.a_wg = P;
+      const size_t emr_lds = emr_lds_bytes<M, T>();
+      const int64_t per = EM_LANES * P;
+      const dim3 grid((unsigned)(((sc.B + per - 1) / per) * P)), block(EM_LANES);
+#define EXCENV_EMR_CASE(SOLV)                                                                                                 \
+  case SOLV:                                                                                                                  \
+    if (sc.semantics == EXCENV_SEM_AHEAD) EXCENV_LAUNCH_DYN((sim_ahead_emr_kernel<M, T, SOLV, true>), grid, block, emr_lds, sc.stream, kr); \
+    else EXCENV_LAUNCH_DYN((sim_ahead_emr_kernel<M, T, SOLV, false>), grid, block, emr_lds, sc.stream, kr);             \
+    break;
+      switch (sc.solver) {
+        EXCENV_EMR_CASE(EXCENV_EULER)
+        EXCENV_EMR_CASE(EXCENV_RK4)
+        EXCENV_EMR_CASE(EXCENV_TSIT5)
+        default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
+      }
+#undef EXCENV_EMR_CASE
+      return check_launch("excenv_sim_ahead (env-major fused, register ring)");
+    }
+  }
+  if (sc.em_mode >= 2) {  // decided by the caller (em_fused_eligible): fused env-major kernel, one wave per 64 envs,
                           // TK steps staged in LDS, per-env contiguous runs written out
     const size_t lds = em_lds_elems<T>(M::A, M::S, M::O) * sizeof(T);
     const dim3 grid((unsigned)((sc.B + EM_LANES - 1) / EM_LANES)), block(EM_LANES);

@@ -127,8 +127,10 @@ typedef struct {
  *                    enough to fill the chip that way, else one env per lane), 1 / 2 / 4 = forced. Ignored (always 1) by
  *                    excenv_gym_step and by every call that needs the general instantiation (per-env property arrays,
  *                    gym trajectories, row-major buffers)
- *   env_major_mode : env-major (row-major) buffers — 0: fused LDS time-tile kernel when both layouts are env-major,
- *                    substeps == 1 and the tile fits LDS; 1: never (workspace + transposes, or generic strides)
+ *   env_major_mode : env-major (row-major) buffers — 0: a fused kernel when both layouts are env-major and substeps == 1
+ *                    (the register-ring form for large batches of broadcast-property environments with 128-byte aligned
+ *                    trajectory arrays, else the LDS-ring form); 1: never (workspace + transposes, or generic strides);
+ *                    2: fused, LDS-ring form only; 3: fused, register-ring form whenever its preconditions hold
  *   lds_pad_bytes  : extra dynamic LDS per sim_ahead workgroup (caps resident workgroups per CU; occupancy experiments)
  *   reserved       : must be 0 */
 typedef struct {

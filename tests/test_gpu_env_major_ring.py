@@ -1,0 +1,71 @@
+"""The register-ring form of the fused env-major trajectory kernel (csrc/kernels_emr.hpp): whole-line stores out of a per-lane
+window of saved states. Reference row-major arrays (core_env.py:571-616: observations [B, K+1, O], state leaves [B, K+1]) must
+hold the same bits as the LDS-ring form and as the lane-major kernel, for every window phase (head / whole / tail windows),
+ragged batches (waves with idle lanes) and both dtypes. ``-m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+from exciting_environments_amd import _native
+from helpers import NP_DTYPE, make_env, random_state, to_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(env, st, acts, mode):
+    env.traj_layout = "env_major"
+    env.env_major_fused, env.env_major_workspace = True, True
+    env.launch_opts = _native.launch_opts(env_major_mode=mode)
+    out = env.vmap_sim_ahead(to_state(env, st), acts, env.tau, env.tau)
+    torch.cuda.synchronize()
+    return out
+
+
+def _same(env, a, b):
+    assert a[0].is_contiguous() and torch.equal(a[0], b[0])
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(a[2].physical_state, n), getattr(b[2].physical_state, n))
+        if a[1] is not None:
+            assert torch.equal(getattr(a[1].physical_state, n), getattr(b[1].physical_state, n))
+
+
+@pytest.mark.parametrize("env_name,dtype,solver", [
+    ("pmsm", torch.float32, "euler"), ("pmsm", torch.float64, "euler"), ("pmsm", torch.float32, "tsit5"),
+    ("pendulum", torch.float32, "euler"), ("pendulum", torch.float64, "rk4"), ("fluid_tank", torch.float32, "euler"),
+    ("cartpole", torch.float32, "euler"), ("acrobot", torch.float64, "euler"), ("mass_spring_damper", torch.float32, "tsit5")])
+@pytest.mark.parametrize("B,K", [(4096, 100), (4096 + 192, 100), (2048, 127), (2049, 64), (4096, 7), (1000, 33), (4096, 160)])
+def test_register_ring_equals_lds_ring_and_lane_major(env_name, dtype, solver, B, K):
+    if (B * K * (2 if env_name == "pmsm" else 1) * (4 if dtype is torch.float32 else 8)) % 16:
+        pytest.skip("the fused kernels need an action array made of whole 16-byte pieces")
+    env, props, keep, spec = make_env(env_name, B, dtype, solver=solver)
+    st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=41)
+    acts = torch.as_tensor(np.random.default_rng(42).uniform(-1, 1, (B, K, env.action_dim)).astype(NP_DTYPE[dtype]), device=env.device)
+    lds = _run(env, st, acts, 2)
+    ring = _run(env, st, acts, 3)
+    _same(env, ring, lds)
+    env.traj_layout, env.launch_opts = "lane_major", None
+    lane = env.vmap_sim_ahead(to_state(env, st), acts, env.tau, env.tau)
+    _same(env, ring, lane)
+
+
+@pytest.mark.parametrize("semantics", ["ahead", "step"])
+def test_register_ring_both_semantics_and_observations_only(semantics):
+    B, K = 4096, 75
+    env, props, keep, spec = make_env("pmsm", B, torch.float32)
+    env.sim_ahead_semantics = semantics
+    st = random_state("pmsm", B, np.float32, spec, seed=43)
+    acts = torch.as_tensor(np.random.default_rng(44).uniform(-1, 1, (B, K, 2)).astype(np.float32), device=env.device)
+    _same(env, _run(env, st, acts, 3), _run(env, st, acts, 2))
+    env.store_state_trajectory = False
+    a, b = _run(env, st, acts, 3), _run(env, st, acts, 2)
+    assert a[1] is None and b[1] is None
+    _same(env, a, b)
+
+
+def test_register_ring_is_what_a_large_default_call_runs():
+    """Default options, a batch large enough for the heuristic: the result equals the forced LDS-ring form."""
+    B, K = 65536, 100
+    env, props, keep, spec = make_env("pmsm", B, torch.float32)
+    st = random_state("pmsm", B, np.float32, spec, seed=45)
+    acts = torch.as_tensor(np.random.default_rng(46).uniform(-1, 1, (B, K, 2)).astype(np.float32), device=env.device)
+    _same(env, _run(env, st, acts, 0), _run(env, st, acts, 2))
