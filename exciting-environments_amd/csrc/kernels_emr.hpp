@@ -33,6 +33,9 @@ template <typename T, int W> struct EmrVec { typedef T type __attribute__((ext_v
 // leaves, 64-byte runs (half lines, written 4 lanes x 16 bytes) for the others. PMSM in fp64 does not fit either way (7 leaves
 // x 8 doubles + a double-precision integration: > 100 registers spilled) and stays on the LDS-ring kernel.
 template <class M, typename T> constexpr int emr_rows() { return (M::S > 3 ? 64 : 128) / (int)sizeof(T); }
+// A state leaf that never changes along a trajectory needs no window: PMSM's omega_el (pmsm_env.py:509-523: the ODE has no
+// equation for it; sim_ahead keeps it constant, :785-791). -1: none.
+template <class M> constexpr int emr_const_leaf() { return M::IS_PMSM ? 6 : -1; }
 template <class M, typename T> constexpr bool emr_supported() { return !M::HAS_LUT && !(M::S > 4 && sizeof(T) == 8); }
 
 // LDS bytes per wave: the transposition buffer (64 lanes x one run) and the action line slots (64 x 128 bytes)
@@ -59,7 +62,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   static_assert(WL % A == 0 && VW % A == 0, "an action row must not straddle a 16-byte piece");
   using Vec = typename EmrVec<T, W>::type;
   extern __shared__ __align__(16) unsigned char excenv_emr_smem[];
-  T* const xp = reinterpret_cast<T*>(excenv_emr_smem);  // [64 lanes][NPC pieces], piece p of lane l at position p ^ (l % NPC)
+  T* const xp = reinterpret_cast<T*>(excenv_emr_smem);  // [NPC pieces][64 lanes]: piece p of lane l at lane position l ^ p (both directions conflict-free)
   T* const slot_a = xp + EM_LANES * W;                  // [8 pieces][64 lanes]: the action line each lane is in
 
   const int lane = threadIdx.x;
@@ -123,9 +126,15 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   };
 
   if (env0 >= ka.B) return;  // no barrier is ever used: a wave without environments may leave
-  Vec ring[S];
+  constexpr int CL = emr_const_leaf<M>();  // this leaf's saved value is st[CL] at every step
+  constexpr int NR = S - (CL >= 0 ? 1 : 0);
+  Vec ring[NR];
 #pragma unroll
-  for (int j = 0; j < S; ++j) ring[j] = (Vec)(T(0));
+  for (int j = 0; j < NR; ++j) ring[j] = (Vec)(T(0));
+  auto ring_get = [&](int j, int s_) __attribute__((always_inline)) -> T {  // j: compile-time constant at every call
+    if (j == CL) return st[CL >= 0 ? CL : 0];
+    return ring[(CL >= 0 && j > CL) ? j - 1 : j][s_];
+  };
   T* const obs_base = ka.obs;
 
   // ---- flush the ring slots [s_lo, s_hi]; slot 0 is row n_slot0 of every environment of the wave ----
@@ -141,31 +150,34 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
       T v[VW];
 #pragma unroll
       for (int h = 0; h < VW; ++h) v[h] = src[i * VW + h];
-      store_v<T, VW>(xp + (lane * NPC + (i ^ pi)) * VW, v);
+      store_v<T, VW>(xp + (i * EM_LANES + (lane ^ i)) * VW, v);
     }
     wave_sync();
   };
-  auto emit_lines = [&](T* p0, int64_t q_stride, bool fast, int s_lo, int s_hi, auto&& slot_of) __attribute__((always_inline)) {
+  // Addresses: a wave-uniform base (scalar registers) plus a 32-bit lane offset — global_store with an SGPR base. Per-lane 64-bit
+  // pointers per leaf were hoisted out of the step loop by the compiler, spilled, and every reload (scratch_load + s_waitcnt
+  // vmcnt(0)) then waited for the previous leaf's stores to complete.
+  auto emit_lines = [&](T* ubase, int64_t q_stride, unsigned lane_off, bool fast, int s_lo, int s_hi, auto&& slot_of) __attribute__((always_inline)) {
     if (fast) {  // whole window, whole wave: eight reads, eight whole-line stores, no lane-dependent control flow
       T v[NPC][VW];
 #pragma unroll
-      for (int q = 0; q < NPC; ++q) load_v<T, VW>(xp + ((g8 + q) * NPC + (pi ^ q)) * VW, v[q]);
+      for (int q = 0; q < NPC; ++q) load_v<T, VW>(xp + (pi * EM_LANES + ((g8 + q) ^ pi)) * VW, v[q]);
 #pragma unroll
       for (int q = 0; q < NPC; ++q) {
 #if EXCENV_EMR_DEBUG & 4
-        asm volatile("" ::"v"(v[q][0]), "v"(v[q][VW - 1]), "v"(p0 + q * q_stride));
+        asm volatile("" ::"v"(v[q][0]), "v"(v[q][VW - 1]), "v"(lane_off));
 #elif EXCENV_EMR_NT
-        store_stream<T, VW>(p0 + q * q_stride, v[q]);
+        store_stream<T, VW>(ubase + q * q_stride + lane_off, v[q]);
 #else
-        store_v<T, VW>(p0 + q * q_stride, v[q]);
+        store_v<T, VW>(ubase + q * q_stride + lane_off, v[q]);
 #endif
       }
     } else {
 #pragma unroll
       for (int q = 0; q < NPC; ++q) {
         T v[VW];
-        load_v<T, VW>(xp + ((g8 + q) * NPC + (pi ^ q)) * VW, v);
-        T* const p = p0 + q * q_stride;
+        load_v<T, VW>(xp + (pi * EM_LANES + ((g8 + q) ^ pi)) * VW, v);
+        T* const p = ubase + q * q_stride + lane_off;
         if (env_g8 + (int64_t)P * q < ka.B) {
           bool ok[VW], all = true, any = false;
 #pragma unroll
@@ -189,15 +201,17 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   };
   auto flush = [&](int s_lo, int s_hi, int64_t n_slot0) __attribute__((always_inline)) {
     const bool fast = full_wave && (s_lo == 0) && (s_hi == W - 1);
-    const int64_t row_g8 = env_g8 * rowlen + n_slot0;  // (environment, slot 0) of the group's first lane, in rows
+    const int64_t row_u = env0 * rowlen + n_slot0;                               // (lane 0's environment, slot 0), in rows: uniform
+    const unsigned lane_rows = (unsigned)((int64_t)P * g8 * rowlen);              // rows between lane 0's and the group's first environment
     if (with_states) {
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         T ln[W];
 #pragma unroll
-        for (int h = 0; h < W; ++h) ln[h] = ring[j][h];
+        for (int h = 0; h < W; ++h) ln[h] = ring_get(j, h);
         put_pieces(ln);
-        emit_lines(ka.straj[j] + row_g8 + pi * VW, (int64_t)P * rowlen, fast, s_lo, s_hi, [&](int h) { return pi * VW + h; });
+        emit_lines(ka.straj[j] + row_u, (int64_t)P * rowlen, lane_rows + (unsigned)(pi * VW), fast, s_lo, s_hi,
+                   [&](int h) { return pi * VW + h; });
       }
     }
     // observation lines: line l of the window holds rows [l * RPO, (l + 1) * RPO)
@@ -209,15 +223,15 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
       for (int t = 0; t < RPO; ++t) {
         T fs[S], ob[O];
 #pragma unroll
-        for (int j = 0; j < S; ++j) fs[j] = ring[j][l * RPO + t];
+        for (int j = 0; j < S; ++j) fs[j] = ring_get(j, l * RPO + t);
         M::observe(fs, c, ob);
 #pragma unroll
         for (int q = 0; q < O; ++q) pk[t * O + q] = ob[q];
       }
       put_pieces(pk);
       // element (row s, column o) of the window sits at ((env * rowlen + n_slot0 + s) * O + o); line l starts at s = l * RPO
-      emit_lines(obs_base + row_g8 * O + (int64_t)l * W + pi * VW, (int64_t)P * rowlen * O, fast, s_lo, s_hi,
-                 [&](int h) { return l * RPO + (pi * VW + h) / O; });
+      emit_lines(obs_base + row_u * O + (int64_t)l * W, (int64_t)P * rowlen * O, lane_rows * (unsigned)O + (unsigned)(pi * VW), fast, s_lo,
+                 s_hi, [&](int h) { return l * RPO + (pi * VW + h) / O; });
     }
   };
 
@@ -262,7 +276,8 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
       }
     }
 #pragma unroll
-    for (int j = 0; j < S; ++j) ring[j][slot] = sv[j];
+    for (int j = 0; j < S; ++j)
+      if (j != CL) ring[(CL >= 0 && j > CL) ? j - 1 : j][slot] = sv[j];
     if (!(EXCENV_EMR_DEBUG & 2) && (slot == W - 1 || n == N)) {
       const int back = (int)((n < slot) ? n : slot);  // rows of the window before row n
       flush(slot - back, slot, n - slot);

@@ -456,7 +456,8 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     auto period = [](int64_t x, int64_t m) { int64_t g = m, y = x % m; while (y) { const int64_t t = g % y; g = y; y = t; } return m / g; };
     const int64_t Ps = period(sc.K + 1, W), Pa = period(sc.K * M::A, WL);
     const int64_t P = Ps > Pa ? Ps : Pa;
-    bool ok = ((uintptr_t)ka.obs % 128) == 0 && (sc.em_mode == 4 || sc.B >= 16 * EM_LANES * P);
+    bool ok = ((uintptr_t)ka.obs % 128) == 0 && (sc.em_mode == 4 || sc.B >= 16 * EM_LANES * P) &&
+              EM_LANES * P * (sc.K + 1) * M::O * (int64_t)sizeof(T) < ((int64_t)1 << 31);  // 32-bit lane offsets
     for (int j = 0; j < M::S; ++j) ok &= ka.straj[j] == nullptr || ((uintptr_t)ka.straj[j] % 128) == 0;
     if (ok) {
       SimArgs<T, M> kr = ka;
