@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   const bool deadtime_on = M::IS_PMSM ? (c.P[M::P - 1] > T(0)) : false;
   const bool with_states = ka.straj[0] != nullptr;
 
-  const int64_t N = ka.K;  // substeps == 1 on this path (host); K >= 1 (host)
+  const int N = (int)ka.K;  // substeps == 1 on this path; 1 <= K and 64 * P * (K + 1) * O * sizeof(T) < 2^31 (host)
   const int64_t rowlen = N + 1;
   // wave-uniform window phase: slot of row n in the ring = (ph + n) % W (leaf and observation bases are 128-byte aligned, host)
   const int ph = (int)(((int64_t)r * (rowlen % W)) % W);
@@ -242,17 +242,17 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     park_line(first);
   }
   load_line(1, lineR);
-  int64_t lidx = 0;  // number of the line in the slot
+  int lidx = 0;  // number of the line in the slot
   T a_cur[A], sv[S];
   wave_sync();
   read_row(pha, a_cur);
 
-  for (int64_t n = 0; n <= N; ++n) {
-    const int slot = (int)((ph + n) % W);
+  for (int n = 0; n <= N; ++n) {
+    const int slot = (ph + n) % W;
     // Row n + 1 of the actions (clamped) is what this step still needs (row n is in a_cur). When it starts the next line, that
     // line moves from the registers into the slot and the one after it is requested (wave-uniform).
-    const int64_t k1 = (n + 1 < ka.K) ? n + 1 : ka.K - 1;
-    const int64_t pos1 = pha + k1 * A;
+    const int k1 = (n + 1 < N) ? n + 1 : N - 1;
+    const int pos1 = pha + k1 * A;
     if (!(EXCENV_EMR_DEBUG & 1) && n < N && pos1 / WL != lidx) {
       park_line(lineR);
       ++lidx;
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
       wave_sync();
     }
     T a_nxt[A];  // requested here, used by the integration below: the save in between covers the LDS latency
-    read_row((int)(pos1 % WL), a_nxt);
+    read_row(pos1 % WL, a_nxt);
 #pragma unroll
     for (int j = 0; j < S; ++j) sv[j] = st[j];
     if constexpr (AHEAD) {
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     for (int j = 0; j < S; ++j)
       if (j != CL) ring[(CL >= 0 && j > CL) ? j - 1 : j][slot] = sv[j];
     if (!(EXCENV_EMR_DEBUG & 2) && (slot == W - 1 || n == N)) {
-      const int back = (int)((n < slot) ? n : slot);  // rows of the window before row n
+      const int back = (n < slot) ? n : slot;  // rows of the window before row n
       flush(slot - back, slot, n - slot);
     }
     if (n < N) {

@@ -147,16 +147,18 @@ template <typename T> struct AheadAux {
 
 // jnp.linspace(0, tau * (K - 1), K)[k] as JAX evaluates it (jax.numpy.linspace: start * (1 - s) + stop * s with s = k / (K - 1)
 // for k < K - 1, the end point itself for k == K - 1; start == 0 contributes +0). Wave-uniform: k and K are.
-template <typename T, class M> __device__ __forceinline__ T ahead_time(int64_t k, const Ctx<T, M>& c) {
+template <typename T, class M, typename I> __device__ __forceinline__ T ahead_time(I k, const Ctx<T, M>& c) {
   return (k == c.lin_last) ? c.lin_stop : c.lin_stop * (T(k) / c.lin_div);
 }
 
 // One solver step of the raw ODE state, reference _ode_solver_simulate_ahead structure (SEM_AHEAD):
 // no wrap / clip of the carried state; PMSM clips with the predicted angle eps0 + linspace(0, tau*(K-1), K)[k] * omega
 // (pmsm_env.py:719-722) and applies actions_dead[k] (:766-777).
-template <class M, int SOLVER, typename T>
-__device__ __forceinline__ void env_advance_raw(T (&st)[M::S], const T (&a)[M::A], const T (&a1)[M::A], int64_t k,
-                                                int64_t k1, const Ctx<T, M>& c, AheadAux<T>& aux,
+// I: the integer type of the action row indices (int64_t, or int in kernels whose host side bounds K: a 32-bit index converts to
+// T in one instruction and compares in the scalar unit; same values, same bits).
+template <class M, int SOLVER, typename T, typename I>
+__device__ __forceinline__ void env_advance_raw(T (&st)[M::S], const T (&a)[M::A], const T (&a1)[M::A], I k,
+                                                I k1, const Ctx<T, M>& c, AheadAux<T>& aux,
                                                 const T (*q0)[6] = nullptr) {
   T u[M::A];
   T uc[2] = {T(0), T(0)};

@@ -906,6 +906,10 @@ class CoreEnvironment(ABC):
                                                   want_states, out)
         if out is not None:
             raise ValueError("vmap_sim_ahead(out=...) is available for the default lane-major trajectories without gym outputs")
+        isz = 4 if self.dtype is torch.float32 else 8
+        if (self.traj_layout == "env_major" and not want_gym and B > 0 and self.device.type == "cuda"
+                and (OW + (S if want_states else 0)) * (N + 1) * B * isz >= self._PLACED_TRAJ_BYTES):
+            return self._run_sim_ahead_env_major_large(actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub, want_states)
         if self.traj_layout == "lane_major":
             obs_buf = torch.empty((N + 1, OW, B), dtype=self.dtype, device=self.device)
             st_buf = [torch.empty((N + 1, B), dtype=self.dtype, device=self.device) for _ in range(S)] if want_states else None
@@ -993,17 +997,18 @@ class CoreEnvironment(ABC):
     _PLACEMENT_REPLACEMENTS = 2
     _PLACEMENT_SPACER_BYTES = 16 << 30  # a rejected block + this much memory stay allocated while the next block is made
 
-    def _place_state_block(self, obs_buf, B, rows, OW, S, isz, time_launch):
+    def _place_state_block(self, obs_buf, B, rows, OW, S, isz, time_launch, block_shape=None):
         """A [S, rows, B] block for the state leaves of a new set whose traffic, together with the observations', does not fall
         into one physical region (see above). `time_launch(block)` runs the trajectory launch of the current call into
         (obs_buf, block) and returns its time in ms. Returns (block, diagnostics)."""
         dt, dev = self.dtype, self.device
-        block = torch.empty((S, rows, B), dtype=dt, device=dev)
+        block_shape = (S, rows, B) if block_shape is None else block_shape  # env-major sets: (S, padded leaf elements)
+        block = torch.empty(block_shape, dtype=dt, device=dev)
         nbytes = (OW + S) * rows * B * isz
         if (self.trajectory_placement != "auto" or time_launch is None or nbytes < self._PLACED_TRAJ_BYTES
                 or torch.cuda.is_current_stream_capturing()):
             return block, None
-        pkey = (B, rows, OW, S)
+        pkey = (B, rows, OW, S) + (() if len(block_shape) == 3 else ("env_major",))
         known = self._placement_best.get(pkey)
         tried, spacers = [], []
         try:
@@ -1027,7 +1032,7 @@ class CoreEnvironment(ABC):
                 if sp is not None:
                     spacers.append(sp)
                 try:
-                    block = torch.empty((S, rows, B), dtype=dt, device=dev)
+                    block = torch.empty(block_shape, dtype=dt, device=dev)
                 except torch.OutOfMemoryError:
                     break
         finally:
@@ -1051,9 +1056,13 @@ class CoreEnvironment(ABC):
             return False
         return [CoreEnvironment._storage_use_count(st._cdata) for st in ts.storages] == ts.use0
 
-    def _traj_set_for(self, B, rows, OW, S, want_states, last_e, isz, launch):
+    def _traj_set_for(self, B, rows, OW, S, want_states, last_e, isz, launch, env_major=False):
+        """env_major: the reference's row-major arrays (observations [B, rows, OW], state leaves [B, rows], every leaf starting on
+        a 128-byte boundary of one block) instead of views of lane-major memory; pooled and placed the same way."""
         dt, dev = self.dtype, self.device
-        key = (B, rows, OW, S, want_states, dt)
+        key = (B, rows, OW, S, want_states, dt) + (("env_major",) if env_major else ())
+        pkey = (B, rows, OW, S) + (("env_major",) if env_major else ())
+        leaf_e = (rows * B * isz + 127) // 128 * 128 // isz if env_major else rows * B  # elements between consecutive leaves
         capturing = torch.cuda.is_current_stream_capturing()
         pooled = (self.trajectory_pool and not capturing and CoreEnvironment._storage_use_count is not None
                   and CoreEnvironment._tensor_use_count is not None)
@@ -1063,7 +1072,7 @@ class CoreEnvironment(ABC):
                 if ts.key == key and self._traj_set_is_free(ts, stream):
                     # a dead set whose placement turned out clearly slower than what a later search found is not worth keeping:
                     # it is dropped and a new one is placed against the better time (at most _PLACEMENT_REPLACEMENTS times)
-                    best = self._placement_best.get((B, rows, OW, S))
+                    best = self._placement_best.get(pkey)
                     ms = (ts.placement or {}).get("chosen_ms")
                     if (best is not None and ms is not None and ms > 1.03 * best and (OW + S) * rows * B * isz >= (1 << 30)
                             and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS and launch is not None):
@@ -1075,7 +1084,7 @@ class CoreEnvironment(ABC):
             self._traj_sets = [t for t in self._traj_sets if t.key == key][-(self._TRAJ_POOL_SETS - 1):] if self._TRAJ_POOL_SETS > 1 else []
         ts = CoreEnvironment._TrajSet()
         ts.key = key
-        ts.obs_buf = torch.empty((rows, OW, B), dtype=dt, device=dev)
+        ts.obs_buf = torch.empty((B, rows, OW) if env_major else (rows, OW, B), dtype=dt, device=dev)
         ts.placement = None
         ts.lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
         lb = ts.lbuf.data_ptr()
@@ -1083,7 +1092,7 @@ class CoreEnvironment(ABC):
         ts.obs_ptr = ts.obs_buf.data_ptr()
         if want_states:
             def time_launch(block):
-                ptrs = _native.ptr_array([block.data_ptr() + j * rows * B * isz for j in range(S)])
+                ptrs = _native.ptr_array([block.data_ptr() + j * leaf_e * isz for j in range(S)])
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
                 launch(ts.obs_ptr, ptrs, ts.last_ptrs)  # warm (clocks, TLB)
                 for e in ev[:-1]:  # three timed launches, the fastest counts: the first ones of a process run a few % slow
@@ -1093,14 +1102,18 @@ class CoreEnvironment(ABC):
                 ev[-1].synchronize()
                 return min(float(a.elapsed_time(b)) for a, b in zip(ev[:-1], ev[1:]))
 
-            ts.st_buf, ts.placement = self._place_state_block(ts.obs_buf, B, rows, OW, S, isz, time_launch if launch is not None else None)
+            ts.st_buf, ts.placement = self._place_state_block(ts.obs_buf, B, rows, OW, S, isz, time_launch if launch is not None else None,
+                                                              (S, leaf_e) if env_major else None)
             self.last_placement = ts.placement
             sb = ts.st_buf.data_ptr()
-            ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (rows * B, 1, B)).unbind(0))
-            ts.traj_ptrs = _native.ptr_array([sb + j * rows * B * isz for j in range(S)])
+            if env_major:
+                ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (leaf_e, rows, 1)).unbind(0))
+            else:
+                ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (rows * B, 1, B)).unbind(0))
+            ts.traj_ptrs = _native.ptr_array([sb + j * leaf_e * isz for j in range(S)])
         else:
             ts.st_buf, ts.st_views, ts.traj_ptrs = None, None, None
-        ts.observations = ts.obs_buf.permute(2, 0, 1)
+        ts.observations = ts.obs_buf[:] if env_major else ts.obs_buf.permute(2, 0, 1)  # a view object of its own (liveness test)
         ts.last = tuple(ts.lbuf[:, :B].unbind(0))
         ts.tens = (ts.observations,) + (ts.st_views or ()) + ts.last
         ts.storages = [t.untyped_storage() for t in ((ts.obs_buf, ts.lbuf) + ((ts.st_buf,) if want_states else ()))]
@@ -1111,6 +1124,44 @@ class CoreEnvironment(ABC):
             ts.use0 = [CoreEnvironment._storage_use_count(st._cdata) for st in ts.storages]
             self._traj_sets.append(ts)
         return ts
+
+    def _run_sim_ahead_env_major_large(self, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub, want_states):
+        """Row-major (reference-shaped) trajectories of at least _PLACED_TRAJ_BYTES: the fused env-major kernels write scattered
+        runs and depend on where observations and state leaves lie even more than the lane-major kernel does
+        (tools/em_placement.py: 7.0 ... 10.9 ms for the same launch), so these sets are pooled and placed like the lane-major
+        ones."""
+        S, OW = self.physical_state_dim, self._obs_dim()
+        N = K * sub
+        rows = N + 1
+        dt, dev = self.dtype, self.device
+        isz = 4 if dt is torch.float32 else 8
+        last_e = (B * isz + 15) // 16 * 16 // isz
+        opts = self.launch_opts
+        if not self.env_major_fused:
+            opts = _native.launch_opts(opts.envs_per_lane if opts else 0, 1, opts.lds_pad_bytes if opts else 0)
+        ws = ws_ptr = None
+        ws_bytes = 0
+        if self.env_major_workspace:
+            ws_bytes = _native.sim_ahead_workspace_bytes(self.ENV_ID, dt, B, K, sub, len(self.control_state), a_layout,
+                                                         _native.LAYOUT_ENV_MAJOR, want_states)
+            if ws_bytes > 0:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)  # stream-ordered: free to die when this function returns
+                ws_ptr = ws.data_ptr()
+        sem = _native.SEM_AHEAD if self.sim_ahead_semantics == "ahead" else _native.SEM_STEP
+        st_in_ptrs = _native._ptrs(st_in)
+
+        def launch(o_ptr, t_ptrs, l_ptrs):
+            with _native._on_device(dev):
+                _native.sim_ahead_raw(self.ENV_ID, self._solver.id, 0 if dt is torch.float32 else 1, B, K, sub, ctypes.byref(props),
+                                      ctypes.byref(control) if control is not None else None, float(obs_stepsize), float(self.tau),
+                                      st_in_ptrs, actions.data_ptr() if K > 0 else None, a_layout, o_ptr,
+                                      t_ptrs if want_states else None, _native.LAYOUT_ENV_MAJOR, l_ptrs, sem, ws_ptr,
+                                      ws_bytes if ws_ptr is not None else 0, None if opts is None else ctypes.byref(opts),
+                                      _native._raw_stream(dev))
+
+        ts = self._traj_set_for(B, rows, OW, S, want_states, last_e, isz, launch, env_major=True)
+        launch(ts.obs_ptr, ts.traj_ptrs, ts.last_ptrs)
+        return ts.observations, ts.st_views, ts.last, N
 
     # Trajectories up to this size come out of ONE allocation (observations, state leaves and last_state are views of it):
     # at RL / MPC batch sizes the launch takes ~100 us and 2 S + 1 allocator calls plus as many view objects cost as much.

@@ -196,3 +196,36 @@ def test_placement_search_logic_with_scripted_timings():
     env.trajectory_placement = "off"
     block, diag, seen = run([1.0])
     assert diag is None and seen == []
+
+
+@pytest.mark.parametrize("env_name", ["pmsm", "pendulum"])
+def test_env_major_sets_are_pooled_and_equal_the_unpooled_run(env_name):
+    """Reference-shaped (row-major) trajectories go through the same pooled, placed sets: contiguous arrays, two alternating
+    sets in a chained run, the bits of the plain allocation per call."""
+    K, B = 16, 4096
+    env, s0 = _env(env_name, B=B)
+    ref_env, r0 = _env(env_name, B=B, pool=False, placed=False)
+    env.traj_layout = ref_env.traj_layout = "env_major"
+    ref_env._PLACED_TRAJ_BYTES = 1 << 62  # the plain path of the small env-major outputs
+    g = torch.Generator(device=env.device)
+    ptrs, state, rstate = [], s0, r0
+    for i in range(6):
+        g.manual_seed(300 + i)
+        a = (torch.rand((B, K, env.action_dim), generator=g, device=env.device, dtype=env.dtype) * 2 - 1)
+        obs, states, state = env.vmap_sim_ahead(state, a, env.tau, env.tau)
+        robs, rstates, rstate = ref_env.vmap_sim_ahead(rstate, a, env.tau, env.tau)
+        assert obs.is_contiguous() and torch.equal(obs, robs)
+        for x, y in zip(_leaves(env, states), _leaves(ref_env, rstates)):
+            assert x.is_contiguous() and x.data_ptr() % 128 == 0 and torch.equal(x, y)
+        for x, y in zip(_leaves(env, state), _leaves(ref_env, rstate)):
+            assert torch.equal(x, y)
+        ptrs.append(obs.data_ptr())
+        del obs, states
+    assert len(set(ptrs)) == 2 and ptrs[0] == ptrs[2] == ptrs[4] and ptrs[1] == ptrs[3] == ptrs[5]
+    held = env.vmap_sim_ahead(s0, a, env.tau, env.tau)[0]
+    keep = held.clone()
+    for i in range(3):
+        o2 = env.vmap_sim_ahead(s0, a * 0.5, env.tau, env.tau)[0]
+        assert o2.data_ptr() != held.data_ptr()
+        del o2
+    assert torch.equal(held, keep)

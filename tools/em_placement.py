@@ -67,5 +67,12 @@ up = lambda x, a: (x + a - 1) // a * a
 pitch = up(leaf_bytes, 2 * MiB)
 base = up(obs_bytes, 2 * MiB)
 case("packed at 0", 0, [base + j * pitch for j in range(S)])
-case("leaves 32 GiB apart from 8, obs at 216", 216 * GiB, [8 * GiB + j * 32 * GiB for j in range(S)])
+case("obs | 16 GiB | leaves packed", 0, [32 * GiB + j * pitch for j in range(S)])
+case("obs | leaves packed at 64", 0, [64 * GiB + j * pitch for j in range(S)])
+case("leaves 4 GiB apart from 16", 0, [16 * GiB + j * 4 * GiB for j in range(S)])
+case("leaves 8 GiB apart from 16", 0, [16 * GiB + j * 8 * GiB for j in range(S)])
+case("leaves 16 GiB apart from 16", 0, [16 * GiB + j * 16 * GiB for j in range(S)])
 case("leaves 30 GiB apart from 2, obs at 216", 216 * GiB, [2 * GiB + j * 30 * GiB for j in range(S)])
+case("leaves alternate two areas 64 GiB apart", 0, [16 * GiB + (j % 2) * 64 * GiB + (j // 2) * pitch for j in range(S)])
+case("leaves in three areas 48 GiB apart", 0, [16 * GiB + (j % 3) * 48 * GiB + (j // 3) * pitch for j in range(S)])
+case("obs in the middle (100), leaves packed at 0", 100 * GiB, [j * pitch for j in range(S)])
