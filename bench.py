@@ -246,7 +246,7 @@ def measure_traffic_live(args):
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "already running under a profiler"
     probe = os.path.join(ROOT, "tools", "traffic_probe.py")
-    hot = "step_kernel" if args.path == "step" else ("sim_ahead_em_kernel" if args.traj_layout == "env_major" and args.action_layout == "env_major" else "sim_ahead_kernel")
+    hot = "step_kernel" if args.path == "step" else ("sim_ahead_em" if args.traj_layout == "env_major" and args.action_layout == "env_major" else "sim_ahead_kernel")
     vals, calib = {}, {}
     tmp = tempfile.mkdtemp(prefix="excenv_traffic_", dir="/tmp")
     try:
@@ -570,7 +570,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "sim_ahead_kernel" if args.path == "sim_ahead" else "step_kernel", "kernel_ms": kernel_ms,
+                "kernel": ("step_kernel" if args.path == "step" else ("sim_ahead_emr_kernel / sim_ahead_em_kernel (env-major fused forms)" if args.traj_layout == "env_major" and args.action_layout == "env_major" else "sim_ahead_kernel")), "kernel_ms": kernel_ms,
                 "kernel_ms_min_median_max": ([float(np.min(per_step_ms)), float(np.median(per_step_ms)), float(np.max(per_step_ms))]
                                              if args.steps else None),  # spread over the timed steps (buffer placement)
                 "kernel_ms_spread_pct": (100.0 * (float(np.max(per_step_ms)) - float(np.min(per_step_ms))) / float(np.median(per_step_ms))

@@ -241,8 +241,9 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     load_line(0, first);
     park_line(first);
   }
-  load_line(1, lineR);
   int lidx = 0;  // number of the line in the slot
+  const int last_line = (pha + (N - 1) * A) / WL;  // the line that holds the lane's last action row (wave-uniform)
+  load_line(last_line < 1 ? last_line : 1, lineR);
   T a_cur[A], sv[S];
   wave_sync();
   read_row(pha, a_cur);
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     if (!(EXCENV_EMR_DEBUG & 1) && n < N && pos1 / WL != lidx) {
       park_line(lineR);
       ++lidx;
-      load_line(lidx + 1, lineR);
+      load_line(lidx + 1 < last_line ? lidx + 1 : last_line, lineR);  // never past the lane's own rows (a neighbour's line: fetched for nothing)
       wave_sync();
     }
     T a_nxt[A];  // requested here, used by the integration below: the save in between covers the LDS latency
