@@ -46,6 +46,23 @@ if bench is not None:
         lines += [f"* rocprofv3 --kernel-trace --stats average of the dominant kernel ({hot_avg_ms[3]} calls, profiled run): "
                   f"{hot_avg_ms[0]:.4f} ms -> {gbs:.0f} GB/s algorithmic = **{gbs / 8000.0:.4f} of the 8 TB/s HBM peak** "
                   f"(bench line, un-profiled: {rf['frac']:.4f}; the profiled run is another process: its buffers sit elsewhere in physical memory, which moves this kernel by up to 25 %, DESIGN.md §6, and profiled passes run at a slightly lower clock)"]
+        # the timed steps alone: the last `steps` dispatches of that kernel in the trace (the earlier ones are warm-up and the
+        # placement probes of new output sets, core_env.py — several of those run in the slow level by design)
+        try:
+            tb = json.loads([l for l in open(os.path.join(src, "bench_under_trace.json")).read().splitlines() if l.startswith("{")][-1])
+            nsteps = int(tb["steps"])
+            durs = []
+            for f in find("trace", "*kernel_trace.csv"):
+                rows = [r for r in csv.DictReader(open(f)) if r.get("Kernel_Name", "") == hot_avg_ms[2]]
+                rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+                durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows][-nsteps:]
+            if durs:
+                avg = sum(durs) / len(durs)
+                gbs = rf["algorithmic_bytes_per_launch"] / (avg * 1e-3) / 1e9
+                lines += [f"* the {len(durs)} timed steps of the profiled run alone (last dispatches of the trace): average {avg:.4f} ms "
+                          f"(min {min(durs):.4f}, max {max(durs):.4f}) -> {gbs:.0f} GB/s = **{gbs / 8000.0:.4f}**"]
+        except Exception as e:  # noqa: BLE001
+            lines += [f"* (timed steps of the profiled run: not available: {e})"]
     lines.append("")
 # ---- kernel stats ------------------------------------------------------------------------------
 for f in find("trace", "*kernel_stats.csv"):
