@@ -69,3 +69,14 @@ def test_register_ring_is_what_a_large_default_call_runs():
     st = random_state("pmsm", B, np.float32, spec, seed=45)
     acts = torch.as_tensor(np.random.default_rng(46).uniform(-1, 1, (B, K, 2)).astype(np.float32), device=env.device)
     _same(env, _run(env, st, acts, 0), _run(env, st, acts, 2))
+
+
+def test_env_major_mode_values_are_validated():
+    env, props, keep, spec = make_env("pendulum", 256, torch.float32)
+    st = random_state("pendulum", 256, np.float32, spec, seed=1)
+    acts = torch.zeros((256, 8, 1), device=env.device)
+    for bad in (-1, 4):
+        with pytest.raises(RuntimeError, match="env_major_mode must be 0, 1, 2 or 3"):
+            _run(env, st, acts, bad)
+    for ok in (0, 1, 2, 3):
+        _run(env, st, acts, ok)
