@@ -27,19 +27,31 @@ namespace excenv {
 
 template <typename T, int W> struct EmrVec { typedef T type __attribute__((ext_vector_type(W))); };
 
+// Leaves that need no window: one that never changes along a trajectory — PMSM's omega_el (pmsm_env.py:509-523: the ODE has
+// no equation for it; sim_ahead keeps it constant, :785-791) — and one that is a function of other saved leaves: PMSM's torque
+// in the reference-structured trajectory, where every saved row is post-processed (pmsm_env.py:573-578, 680-688: torque from
+// the saved currents; the same device function M::torque here). On the step-semantics path row 0 carries the caller's torque
+// as it came in, so there it stays in the ring. -1: none.
+template <class M> constexpr int emr_const_leaf() { return M::IS_PMSM ? 6 : -1; }
+template <class M, bool AHEAD> constexpr int emr_derived_leaf() { return (M::IS_PMSM && AHEAD) ? 5 : -1; }
+template <class M, bool AHEAD> constexpr int emr_ring_leaves() {
+  return M::S - (emr_const_leaf<M>() >= 0 ? 1 : 0) - (emr_derived_leaf<M, AHEAD>() >= 0 ? 1 : 0);
+}
 // Steps per window. Two waves must share a SIMD (one wave alone leaves the VALU half idle: 9.9 ms for the headline launch with
 // 128-byte windows at one wave per SIMD, 7.7 ms with 64-byte windows at two), so a lane has 256 registers and the windows of
-// ALL state leaves must fit next to the integration's own: 128-byte runs (whole lines) for models with up to three state
-// leaves, 64-byte runs (half lines, written 4 lanes x 16 bytes) for the others. PMSM in fp64 does not fit either way (7 leaves
-// x 8 doubles + a double-precision integration: > 100 registers spilled) and stays on the LDS-ring kernel.
-template <class M, typename T> constexpr int emr_rows() { return (M::S > 3 ? 64 : 128) / (int)sizeof(T); }
-// A state leaf that never changes along a trajectory needs no window: PMSM's omega_el (pmsm_env.py:509-523: the ODE has no
-// equation for it; sim_ahead keeps it constant, :785-791). -1: none.
-template <class M> constexpr int emr_const_leaf() { return M::IS_PMSM ? 6 : -1; }
+// all ring leaves must fit next to the integration's own: 128-byte runs (whole lines, 32 registers per leaf) while the ring
+// stays within EXCENV_EMR_MAX_RING_REGS, else 64-byte runs (half lines, written 4 lanes x 16 bytes). PMSM in fp64 does not
+// fit either way (a double-precision integration next to 6 x 16 registers: > 100 spilled) and stays on the LDS-ring kernel.
+#ifndef EXCENV_EMR_MAX_RING_REGS
+#define EXCENV_EMR_MAX_RING_REGS 128
+#endif
+template <class M, typename T, bool AHEAD> constexpr int emr_rows() {
+  return (emr_ring_leaves<M, AHEAD>() * 32 <= EXCENV_EMR_MAX_RING_REGS ? 128 : 64) / (int)sizeof(T);
+}
 template <class M, typename T> constexpr bool emr_supported() { return !M::HAS_LUT && !(M::S > 4 && sizeof(T) == 8); }
 
 // LDS bytes per wave: the transposition buffer (64 lanes x one run) and the action line slots (64 x 128 bytes)
-template <class M, typename T> constexpr size_t emr_lds_bytes() { return (size_t)EM_LANES * (emr_rows<M, T>() * sizeof(T) + 128); }
+template <class M, typename T, bool AHEAD> constexpr size_t emr_lds_bytes() { return (size_t)EM_LANES * (emr_rows<M, T, AHEAD>() * sizeof(T) + 128); }
 
 #ifndef EXCENV_EMR_DEBUG
 #define EXCENV_EMR_DEBUG 0  // experiments only (results are wrong): 1 never walk to the next action line, 2 no flush, 4 flush without global stores
@@ -50,10 +62,10 @@ template <class M, typename T> constexpr size_t emr_lds_bytes() { return (size_t
 
 // ka.a_wg carries P (environments between consecutive lanes of a wave) on this path.
 template <class M, typename T, int SOLVER, bool AHEAD>
-__global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2, 2))) sim_ahead_emr_kernel(const SimArgs<T, M> ka) {
+__global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2))) sim_ahead_emr_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
   constexpr int VW = 16 / (int)sizeof(T);   // elements per 16-byte piece
-  constexpr int W = emr_rows<M, T>();       // steps per window == elements per run of a state leaf
+  constexpr int W = emr_rows<M, T, AHEAD>();  // steps per window == elements per run of a state leaf
   constexpr int NPC = W / VW;               // 16-byte pieces per run (4 or 8); the lanes of a wave transpose in groups of NPC
   constexpr int WL = 128 / (int)sizeof(T);  // elements per 128-byte line of the action array
   constexpr int NPL = 8;                    // pieces per action line
@@ -126,14 +138,19 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   };
 
   if (env0 >= ka.B) return;  // no barrier is ever used: a wave without environments may leave
-  constexpr int CL = emr_const_leaf<M>();  // this leaf's saved value is st[CL] at every step
-  constexpr int NR = S - (CL >= 0 ? 1 : 0);
+  constexpr int CL = emr_const_leaf<M>();           // this leaf's saved value is st[CL] at every step
+  constexpr int DL = emr_derived_leaf<M, AHEAD>();  // this leaf's saved value is a function of other saved leaves
+  constexpr int NR = emr_ring_leaves<M, AHEAD>();
+  auto ridx = [](int j) constexpr { return j - ((CL >= 0 && j > CL) ? 1 : 0) - ((DL >= 0 && j > DL) ? 1 : 0); };
   Vec ring[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) ring[j] = (Vec)(T(0));
   auto ring_get = [&](int j, int s_) __attribute__((always_inline)) -> T {  // j: compile-time constant at every call
     if (j == CL) return st[CL >= 0 ? CL : 0];
-    return ring[(CL >= 0 && j > CL) ? j - 1 : j][s_];
+    if constexpr (M::IS_PMSM) {
+      if (j == DL) return M::torque(ring[ridx(3)][s_], ring[ridx(4)][s_], c);
+    }
+    return ring[ridx(j)][s_];
   };
   T* const obs_base = ka.obs;
 
@@ -144,12 +161,12 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   const int64_t env_g8 = env0 + (int64_t)P * g8;                      // environment of the group's first lane
   // One line per environment out of the transposition buffer. `line(q)`: pointer to this lane's piece of the line of the
   // group's q-th environment; `slot_of(h)`: ring slot that element h of this lane's piece belongs to.
-  auto put_pieces = [&](const T (&src)[W]) __attribute__((always_inline)) {
+  auto put_pieces = [&](auto&& elem) __attribute__((always_inline)) {  // elem(h): element h of this lane's run, produced piece by piece
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
       T v[VW];
 #pragma unroll
-      for (int h = 0; h < VW; ++h) v[h] = src[i * VW + h];
+      for (int h = 0; h < VW; ++h) v[h] = elem(i * VW + h);
       store_v<T, VW>(xp + (i * EM_LANES + (lane ^ i)) * VW, v);
     }
     wave_sync();
@@ -159,18 +176,21 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   // vmcnt(0)) then waited for the previous leaf's stores to complete.
   auto emit_lines = [&](T* ubase, int64_t q_stride, unsigned lane_off, bool fast, int s_lo, int s_hi, auto&& slot_of) __attribute__((always_inline)) {
     if (fast) {  // whole window, whole wave: eight reads, eight whole-line stores, no lane-dependent control flow
-      T v[NPC][VW];
 #pragma unroll
-      for (int q = 0; q < NPC; ++q) load_v<T, VW>(xp + (pi * EM_LANES + ((g8 + q) ^ pi)) * VW, v[q]);
+      for (int q0 = 0; q0 < NPC; q0 += 4) {  // four reads in flight, four stores: 16 registers
+        T v[4][VW];
 #pragma unroll
-      for (int q = 0; q < NPC; ++q) {
+        for (int q = 0; q < 4; ++q) load_v<T, VW>(xp + (pi * EM_LANES + ((g8 + q0 + q) ^ pi)) * VW, v[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
 #if EXCENV_EMR_DEBUG & 4
-        asm volatile("" ::"v"(v[q][0]), "v"(v[q][VW - 1]), "v"(lane_off));
+          asm volatile("" ::"v"(v[q][0]), "v"(v[q][VW - 1]), "v"(lane_off));
 #elif EXCENV_EMR_NT
-        store_stream<T, VW>(ubase + q * q_stride + lane_off, v[q]);
+          store_stream<T, VW>(ubase + (q0 + q) * q_stride + lane_off, v[q]);
 #else
-        store_v<T, VW>(ubase + q * q_stride + lane_off, v[q]);
+          store_v<T, VW>(ubase + (q0 + q) * q_stride + lane_off, v[q]);
 #endif
+        }
       }
     } else {
 #pragma unroll
@@ -206,10 +226,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     if (with_states) {
 #pragma unroll
       for (int j = 0; j < S; ++j) {
-        T ln[W];
-#pragma unroll
-        for (int h = 0; h < W; ++h) ln[h] = ring_get(j, h);
-        put_pieces(ln);
+        put_pieces([&](int h) __attribute__((always_inline)) { return ring_get(j, h); });
         emit_lines(ka.straj[j] + row_u, (int64_t)P * rowlen, lane_rows + (unsigned)(pi * VW), fast, s_lo, s_hi,
                    [&](int h) { return pi * VW + h; });
       }
@@ -218,24 +235,41 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll 1
     for (int l = 0; l < O; ++l) {
       if ((l + 1) * RPO - 1 < s_lo || l * RPO > s_hi) continue;  // wave-uniform
-      T pk[W];
+      // the rows' observation values go into the transposition buffer piece by piece as they are produced (a whole run of them in
+      // registers would cost W more)
 #pragma unroll
       for (int t = 0; t < RPO; ++t) {
         T fs[S], ob[O];
 #pragma unroll
         for (int j = 0; j < S; ++j) fs[j] = ring_get(j, l * RPO + t);
         M::observe(fs, c, ob);
+        if constexpr (O >= VW) {
 #pragma unroll
-        for (int q = 0; q < O; ++q) pk[t * O + q] = ob[q];
+          for (int m = 0; m < O / VW; ++m) {
+            T v[VW];
+#pragma unroll
+            for (int h = 0; h < VW; ++h) v[h] = ob[m * VW + h];
+            const int i = t * (O / VW) + m;
+            store_v<T, VW>(xp + (i * EM_LANES + (lane ^ i)) * VW, v);
+          }
+        } else {  // several rows per piece: element stores (O = 1 or 2 values per row)
+          const int i = (t * O) / VW;
+#pragma unroll
+          for (int q = 0; q < O; ++q) xp[(i * EM_LANES + (lane ^ i)) * VW + (t * O + q) % VW] = ob[q];
+        }
       }
-      put_pieces(pk);
+      wave_sync();
       // element (row s, column o) of the window sits at ((env * rowlen + n_slot0 + s) * O + o); line l starts at s = l * RPO
       emit_lines(obs_base + row_u * O + (int64_t)l * W, (int64_t)P * rowlen * O, lane_rows * (unsigned)O + (unsigned)(pi * VW), fast, s_lo,
                  s_hi, [&](int h) { return l * RPO + (pi * VW + h) / O; });
     }
   };
 
-  T lineR[WL];  // the prefetched next line
+  // The next action line: prefetched a whole line ahead into 32 registers that stay live through the loop (PMSM: +5 ... 8 % over
+  // loading at the crossing, and its 64-byte windows leave the room), or loaded at the crossing, the SIMD's other waves covering
+  // the latency (the smaller models: those 32 registers are a third wave per SIMD; cart-pole 0.45 -> 0.50, pendulum 0.51 -> 0.54).
+  constexpr bool PREFETCH = M::IS_PMSM;
+  T lineR[PREFETCH ? WL : 1];
   {
     T first[WL];
     load_line(0, first);
@@ -243,7 +277,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   }
   int lidx = 0;  // number of the line in the slot
   const int last_line = (pha + (N - 1) * A) / WL;  // the line that holds the lane's last action row (wave-uniform)
-  load_line(last_line < 1 ? last_line : 1, lineR);
+  if constexpr (PREFETCH) load_line(last_line < 1 ? last_line : 1, lineR);
   T a_cur[A], sv[S];
   wave_sync();
   read_row(pha, a_cur);
@@ -251,13 +285,19 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   for (int n = 0; n <= N; ++n) {
     const int slot = (ph + n) % W;
     // Row n + 1 of the actions (clamped) is what this step still needs (row n is in a_cur). When it starts the next line, that
-    // line moves from the registers into the slot and the one after it is requested (wave-uniform).
+    // line is fetched into the slot (wave-uniform).
     const int k1 = (n + 1 < N) ? n + 1 : N - 1;
     const int pos1 = pha + k1 * A;
     if (!(EXCENV_EMR_DEBUG & 1) && n < N && pos1 / WL != lidx) {
-      park_line(lineR);
       ++lidx;
-      load_line(lidx + 1 < last_line ? lidx + 1 : last_line, lineR);  // never past the lane's own rows (a neighbour's line: fetched for nothing)
+      if constexpr (PREFETCH) {
+        park_line(lineR);
+        load_line(lidx + 1 < last_line ? lidx + 1 : last_line, lineR);  // never past the lane's own rows (a neighbour's line)
+      } else {
+        T nl[WL];
+        load_line(lidx, nl);
+        park_line(nl);
+      }
       wave_sync();
     }
     T a_nxt[A];  // requested here, used by the integration below: the save in between covers the LDS latency
@@ -278,7 +318,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     }
 #pragma unroll
     for (int j = 0; j < S; ++j)
-      if (j != CL) ring[(CL >= 0 && j > CL) ? j - 1 : j][slot] = sv[j];
+      if (j != CL && j != DL) ring[ridx(j)][slot] = sv[j];
     if (!(EXCENV_EMR_DEBUG & 2) && (slot == W - 1 || n == N)) {
       const int back = (n < slot) ? n : slot;  // rows of the window before row n
       flush(slot - back, slot, n - slot);

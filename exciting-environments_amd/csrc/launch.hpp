@@ -452,7 +452,8 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   if ((sc.em_mode == 2 || sc.em_mode == 4) && !general && emr_supported<M, T>() && emr_enabled()) {
     // register-ring form (kernels_emr.hpp): whole-line stores. Needs 128-byte aligned trajectory arrays and enough environments
     // to fill waves whose lanes are P environments apart.
-    constexpr int64_t W = emr_rows<M, T>(), WL = 128 / (int64_t)sizeof(T);
+    const bool ahead = sc.semantics == EXCENV_SEM_AHEAD;
+    const int64_t W = ahead ? emr_rows<M, T, true>() : emr_rows<M, T, false>(), WL = 128 / (int64_t)sizeof(T);
     auto period = [](int64_t x, int64_t m) { int64_t g = m, y = x % m; while (y) { const int64_t t = g % y; g = y; y = t; } return m / g; };
     const int64_t Ps = period(sc.K + 1, W), Pa = period(sc.K * M::A, WL);
     const int64_t P = Ps > Pa ? Ps : Pa;
@@ -462,7 +463,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     if (ok) {
       SimArgs<T, M> kr = ka;
       kr.a_wg = P;
-      const size_t emr_lds = emr_lds_bytes<M, T>();
+      const size_t emr_lds = ahead ? emr_lds_bytes<M, T, true>() : emr_lds_bytes<M, T, false>();
       const int64_t per = EM_LANES * P;
       const dim3 grid((unsigned)(((sc.B + per - 1) / per) * P)), block(EM_LANES);
 #define EXCENV_EMR_CASE(SOLV)                                                                                                 \
