@@ -1,25 +1,27 @@
 // Fused env-major (reference row-major) trajectory kernel, register-ring form (round 3): actions [B][K][A] in, observations
-// [B][N+1][O] and state leaves [B][N+1] out, no transposition pass — and every store instruction writes WHOLE 128-byte lines.
+// [B][N+1][O] and state leaves [B][N+1] out, no transposition pass — and every store instruction writes whole aligned runs
+// (128-byte lines, or 64-byte half lines for the models with many state leaves).
 //
 // Why a second form. The LDS-ring kernel (kernels_em.hpp) keeps TK = 8 saved states per environment in LDS (more does not fit
-// next to enough waves) and so writes the state leaves as 32-byte runs; what that costs is set by the memory system, not by
-// the kernel (tools/em_placement.py: the same launch takes 9.3 ... 13.1 ms depending only on where the leaves lie). Here a lane
-// keeps a whole window of W = 128 / sizeof(T) saved states of ITS environment in registers (one native W-element vector per
-// state leaf, written with a wave-uniform dynamic index: s_set_gpr_idx_on + v_mov), so a window of a leaf is one 128-byte line
-// per environment.
-//   * UNIFORM PHASE. A line of env e's leaf row starts where (e * (N + 1) + n) % W == 0. Lanes of a wave take environments P
+// next to enough waves), writes the state leaves as 32-byte runs and runs 1.2 waves per SIMD; what its stores cost is set by
+// the memory system (tools/em_placement.py: the same launch takes 9.3 ... 13.1 ms depending only on where the leaves lie).
+// Here a lane keeps a window of W saved states of ITS environment in registers — one native W-element vector per state leaf,
+// written with a wave-uniform dynamic index (s_set_gpr_idx_on + v_mov) — so a window of a leaf is one aligned run per
+// environment, LDS holds no history, and two to three waves fit a SIMD.
+//   * UNIFORM PHASE. A run of env e's leaf row starts where (e * (N + 1) + n) % W == 0. Lanes of a wave take environments P
 //     apart, P = the period of that phase in e (a power of two <= W; the host computes it together with the same period of the
-//     action rows' line phase and passes the larger one): all 64 environments of a wave cross their line boundaries at the same
+//     action rows' line phase and passes the larger one): all 64 environments of a wave cross their run boundaries at the same
 //     steps, every ring index and every branch of the flush is wave-uniform.
-//   * FLUSH, once per W steps (plus head and tail): per leaf the 8 sixteen-byte pieces of a lane's line go through an 8 KB LDS
-//     buffer in which each group of 8 lanes transposes its 8 x 8 pieces, so that a store instruction's 8 adjacent lanes write
-//     the 8 pieces of ONE environment's line: 64 lanes x 16 bytes = 8 whole lines per instruction. The observation rows of the
-//     window (O whole lines per environment) are evaluated from the ring at flush time (same device function on the same saved
-//     state as every other kernel: same bits) and leave the same way. Head / tail windows use the same code with a slot range;
-//     pieces cut by the range fall back to element stores.
-//   * ACTIONS. As in the LDS-ring kernel every 128-byte line is fetched once, a whole line (W / A steps) ahead, into registers
-//     and parked in a per-lane LDS slot when the walk crosses into it; with the uniform phase the crossing is wave-uniform.
-// One wave per workgroup (LDS accesses of a wave execute in order: compiler fences only), one wave per SIMD (registers).
+//   * FLUSH, once per W steps (plus head and tail): per leaf the NPC = W * sizeof(T) / 16 sixteen-byte pieces of a lane's run go
+//     through an LDS buffer (64 runs) in which each group of NPC lanes transposes its NPC x NPC pieces, so that a store
+//     instruction's adjacent lanes write the adjacent pieces of ONE environment's run: 64 lanes x 16 bytes = 64 / NPC whole runs
+//     per instruction, non-temporal. The observation rows of the window (O runs per environment) are evaluated from the ring
+//     at flush time (same device function on the same saved state as every other kernel: same bits) and leave the same way.
+//     Head / tail windows and ragged waves use the same code with a slot range; pieces cut by the range fall back to element
+//     stores.
+//   * ACTIONS. As in the LDS-ring kernel every 128-byte line is fetched once and parked in a per-lane LDS slot when the walk
+//     crosses into it; with the uniform phase the crossing is wave-uniform.
+// One wave per workgroup (LDS accesses of a wave execute in order: compiler fences only).
 #pragma once
 #include "kernels_em.hpp"
 
@@ -57,7 +59,7 @@ template <class M, typename T, bool AHEAD> constexpr size_t emr_lds_bytes() { re
 #define EXCENV_EMR_DEBUG 0  // experiments only (results are wrong): 1 never walk to the next action line, 2 no flush, 4 flush without global stores
 #endif
 #ifndef EXCENV_EMR_NT
-#define EXCENV_EMR_NT 1  // whole-line stores of the flush are non-temporal
+#define EXCENV_EMR_NT 1  // whole-run stores of the flush are non-temporal (plain stores: 10 ... 11 ms instead of 7 for the headline launch)
 #endif
 
 // ka.a_wg carries P (environments between consecutive lanes of a wave) on this path.
@@ -159,8 +161,8 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   const int g8 = lane - pi;   // first lane of its group of NPC
   const bool full_wave = env0 + (int64_t)P * (EM_LANES - 1) < ka.B;  // every lane has an environment (wave-uniform)
   const int64_t env_g8 = env0 + (int64_t)P * g8;                      // environment of the group's first lane
-  // One line per environment out of the transposition buffer. `line(q)`: pointer to this lane's piece of the line of the
-  // group's q-th environment; `slot_of(h)`: ring slot that element h of this lane's piece belongs to.
+  // One run per environment through the transposition buffer: put_pieces writes this lane's run, emit_lines stores this lane's
+  // piece of the runs of its group's environments; `slot_of(h)`: ring slot that element h of this lane's piece belongs to.
   auto put_pieces = [&](auto&& elem) __attribute__((always_inline)) {  // elem(h): element h of this lane's run, produced piece by piece
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
@@ -175,7 +177,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   // pointers per leaf were hoisted out of the step loop by the compiler, spilled, and every reload (scratch_load + s_waitcnt
   // vmcnt(0)) then waited for the previous leaf's stores to complete.
   auto emit_lines = [&](T* ubase, int64_t q_stride, unsigned lane_off, bool fast, int s_lo, int s_hi, auto&& slot_of) __attribute__((always_inline)) {
-    if (fast) {  // whole window, whole wave: eight reads, eight whole-line stores, no lane-dependent control flow
+    if (fast) {  // whole window, whole wave: NPC reads, NPC whole-run stores, no lane-dependent control flow
 #pragma unroll
       for (int q0 = 0; q0 < NPC; q0 += 4) {  // four reads in flight, four stores: 16 registers
         T v[4][VW];

@@ -449,7 +449,8 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     set_error("excenv_sim_ahead: internal error: fused env-major kernel selected for an ineligible call");
     return EXCENV_EINVAL;
   }
-  if ((sc.em_mode == 2 || sc.em_mode == 4) && !general && emr_supported<M, T>() && emr_enabled()) {
+  if constexpr (emr_supported<M, T>()) {
+  if ((sc.em_mode == 2 || sc.em_mode == 4) && !general && emr_enabled()) {
     // register-ring form (kernels_emr.hpp): whole-line stores. Needs 128-byte aligned trajectory arrays and enough environments
     // to fill waves whose lanes are P environments apart.
     const bool ahead = sc.semantics == EXCENV_SEM_AHEAD;
@@ -480,6 +481,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
 #undef EXCENV_EMR_CASE
       return check_launch("excenv_sim_ahead (env-major fused, register ring)");
     }
+  }
   }
   if (sc.em_mode >= 2) {  // decided by the caller (em_fused_eligible): fused env-major kernel, one wave per 64 envs,
                           // TK steps staged in LDS, per-env contiguous runs written out
