@@ -1102,7 +1102,9 @@ class CoreEnvironment(ABC):
                 ev[-1].synchronize()
                 return min(float(a.elapsed_time(b)) for a, b in zip(ev[:-1], ev[1:]))
 
-            ts.st_buf, ts.placement = self._place_state_block(ts.obs_buf, B, rows, OW, S, isz, time_launch if launch is not None else None,
+            # a set that is not pooled is written once: probing its placement (four extra launches per candidate) would never pay
+            ts.st_buf, ts.placement = self._place_state_block(ts.obs_buf, B, rows, OW, S, isz,
+                                                              time_launch if (launch is not None and pooled) else None,
                                                               (S, leaf_e) if env_major else None)
             self.last_placement = ts.placement
             sb = ts.st_buf.data_ptr()

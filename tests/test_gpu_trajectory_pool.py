@@ -229,3 +229,13 @@ def test_env_major_sets_are_pooled_and_equal_the_unpooled_run(env_name):
         assert o2.data_ptr() != held.data_ptr()
         del o2
     assert torch.equal(held, keep)
+
+
+def test_unpooled_sets_are_not_probed():
+    """Without the pool every call allocates its outputs and writes them once: the placement search (extra launches) is skipped."""
+    env, s0 = _env("pendulum", B=2048, pool=False, placed=True)
+    a = _actions(env, 8, 11)
+    o1 = env.vmap_sim_ahead(s0, a, env.tau, env.tau)[0]
+    o2 = env.vmap_sim_ahead(s0, a, env.tau, env.tau)[0]
+    assert env.last_placement is None and env._traj_sets == []
+    assert o1.data_ptr() != o2.data_ptr() and torch.equal(o1, o2)
