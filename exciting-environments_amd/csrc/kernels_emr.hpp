@@ -23,6 +23,7 @@
 //     crosses into it; with the uniform phase the crossing is wave-uniform.
 // One wave per workgroup (LDS accesses of a wave execute in order: compiler fences only).
 #pragma once
+#include <type_traits>
 #include "kernels_em.hpp"
 
 namespace excenv {
@@ -52,8 +53,8 @@ template <class M, typename T, bool AHEAD> constexpr int emr_rows() {
 }
 template <class M, typename T> constexpr bool emr_supported() { return !M::HAS_LUT && !(M::S > 4 && sizeof(T) == 8); }
 
-// LDS bytes per wave: the transposition buffer (64 lanes x one run) and the action line slots (64 x 128 bytes)
-template <class M, typename T, bool AHEAD> constexpr size_t emr_lds_bytes() { return (size_t)EM_LANES * (emr_rows<M, T, AHEAD>() * sizeof(T) + 128); }
+// LDS bytes per wave: the transposition buffer (64 lanes x 128 bytes) and the action line slots (64 x 128 bytes)
+template <class M, typename T, bool AHEAD> constexpr size_t emr_lds_bytes() { return (size_t)EM_LANES * (128 + 128); }
 
 #ifndef EXCENV_EMR_DEBUG
 #define EXCENV_EMR_DEBUG 0  // experiments only (results are wrong): 1 never walk to the next action line, 2 no flush, 4 flush without global stores
@@ -69,15 +70,18 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   constexpr int VW = 16 / (int)sizeof(T);   // elements per 16-byte piece
   constexpr int W = emr_rows<M, T, AHEAD>();  // steps per window == elements per run of a state leaf
   constexpr int NPC = W / VW;               // 16-byte pieces per run (4 or 8); the lanes of a wave transpose in groups of NPC
-  constexpr int WL = 128 / (int)sizeof(T);  // elements per 128-byte line of the action array
-  constexpr int NPL = 8;                    // pieces per action line
-  constexpr int RPO = W / O;                // saved rows per observation run
-  static_assert(W % O == 0, "an observation row must divide a run");
+  constexpr int WL = 128 / (int)sizeof(T);  // elements per 128-byte line (action array, observation lines)
+  constexpr int NPL = 8;                    // pieces per line
+  // Observation rows always leave as whole 128-byte lines (8 pieces, groups of 8 lanes), whatever the leaves' run length: the
+  // W rows of a window are W * O / WL lines per environment
+  constexpr int RPO = WL / O;               // saved rows per observation line
+  constexpr int NLO = W / RPO;              // observation lines per window and environment
+  static_assert(WL % O == 0 && W % RPO == 0, "the observation rows of a window must be whole 128-byte lines");
   static_assert(WL % A == 0 && VW % A == 0, "an action row must not straddle a 16-byte piece");
   using Vec = typename EmrVec<T, W>::type;
   extern __shared__ __align__(16) unsigned char excenv_emr_smem[];
   T* const xp = reinterpret_cast<T*>(excenv_emr_smem);  // [NPC pieces][64 lanes]: piece p of lane l at lane position l ^ p (both directions conflict-free)
-  T* const slot_a = xp + EM_LANES * W;                  // [8 pieces][64 lanes]: the action line each lane is in
+  T* const slot_a = xp + EM_LANES * WL;                 // [8 pieces][64 lanes]: the action line each lane is in
 
   const int lane = threadIdx.x;
   const int P = (int)ka.a_wg;
@@ -157,12 +161,10 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   T* const obs_base = ka.obs;
 
   // ---- flush the ring slots [s_lo, s_hi]; slot 0 is row n_slot0 of every environment of the wave ----
-  const int pi = lane % NPC;  // the piece this lane stores
-  const int g8 = lane - pi;   // first lane of its group of NPC
   const bool full_wave = env0 + (int64_t)P * (EM_LANES - 1) < ka.B;  // every lane has an environment (wave-uniform)
-  const int64_t env_g8 = env0 + (int64_t)P * g8;                      // environment of the group's first lane
   // One run per environment through the transposition buffer: put_pieces writes this lane's run, emit_lines stores this lane's
-  // piece of the runs of its group's environments; `slot_of(h)`: ring slot that element h of this lane's piece belongs to.
+  // piece of the runs of its group's environments (groups of NP lanes, NP pieces per run); `slot_of(h)`: ring slot that element
+  // h of this lane's piece belongs to.
   auto put_pieces = [&](auto&& elem) __attribute__((always_inline)) {  // elem(h): element h of this lane's run, produced piece by piece
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
@@ -176,10 +178,13 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   // Addresses: a wave-uniform base (scalar registers) plus a 32-bit lane offset — global_store with an SGPR base. Per-lane 64-bit
   // pointers per leaf were hoisted out of the step loop by the compiler, spilled, and every reload (scratch_load + s_waitcnt
   // vmcnt(0)) then waited for the previous leaf's stores to complete.
-  auto emit_lines = [&](T* ubase, int64_t q_stride, unsigned lane_off, bool fast, int s_lo, int s_hi, auto&& slot_of) __attribute__((always_inline)) {
+  auto emit_lines = [&](auto np_tag, T* ubase, int64_t q_stride, unsigned lane_off, bool fast, int s_lo, int s_hi, auto&& slot_of) __attribute__((always_inline)) {
+    constexpr int NP = decltype(np_tag)::value;
+    const int pi = lane % NP;  // the piece this lane stores
+    const int g8 = lane - pi;  // first lane of its group
     if (fast) {  // whole window, whole wave: NPC reads, NPC whole-run stores, no lane-dependent control flow
 #pragma unroll
-      for (int q0 = 0; q0 < NPC; q0 += 4) {  // four reads in flight, four stores: 16 registers
+      for (int q0 = 0; q0 < NP; q0 += 4) {  // four reads in flight, four stores: 16 registers
         T v[4][VW];
 #pragma unroll
         for (int q = 0; q < 4; ++q) load_v<T, VW>(xp + (pi * EM_LANES + ((g8 + q0 + q) ^ pi)) * VW, v[q]);
@@ -196,11 +201,11 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < NPC; ++q) {
+      for (int q = 0; q < NP; ++q) {
         T v[VW];
         load_v<T, VW>(xp + (pi * EM_LANES + ((g8 + q) ^ pi)) * VW, v);
         T* const p = ubase + q * q_stride + lane_off;
-        if (env_g8 + (int64_t)P * q < ka.B) {
+        if (env0 + (int64_t)P * (g8 + q) < ka.B) {
           bool ok[VW], all = true, any = false;
 #pragma unroll
           for (int h = 0; h < VW; ++h) {
@@ -224,23 +229,25 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   auto flush = [&](int s_lo, int s_hi, int64_t n_slot0) __attribute__((always_inline)) {
     const bool fast = full_wave && (s_lo == 0) && (s_hi == W - 1);
     const int64_t row_u = env0 * rowlen + n_slot0;                               // (lane 0's environment, slot 0), in rows: uniform
-    const unsigned lane_rows = (unsigned)((int64_t)P * g8 * rowlen);              // rows between lane 0's and the group's first environment
     if (with_states) {
+      const int pi = lane % NPC;
+      const unsigned lane_rows = (unsigned)((int64_t)P * (lane - pi) * rowlen);  // rows between lane 0's and the group's first environment
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         put_pieces([&](int h) __attribute__((always_inline)) { return ring_get(j, h); });
-        emit_lines(ka.straj[j] + row_u, (int64_t)P * rowlen, lane_rows + (unsigned)(pi * VW), fast, s_lo, s_hi,
-                   [&](int h) { return pi * VW + h; });
+        emit_lines(std::integral_constant<int, NPC>{}, ka.straj[j] + row_u, (int64_t)P * rowlen, lane_rows + (unsigned)(pi * VW), fast, s_lo,
+                   s_hi, [&](int h) { return pi * VW + h; });
       }
     }
     // observation lines: line l of the window holds rows [l * RPO, (l + 1) * RPO)
+    const int po = lane % NPL;
+    const unsigned lane_rows_o = (unsigned)((int64_t)P * (lane - po) * rowlen);
 #pragma unroll 1
-    for (int l = 0; l < O; ++l) {
+    for (int l = 0; l < NLO; ++l) {
       if ((l + 1) * RPO - 1 < s_lo || l * RPO > s_hi) continue;  // wave-uniform
-      // the rows' observation values go into the transposition buffer piece by piece as they are produced (a whole run of them in
-      // registers would cost W more)
-#pragma unroll
-      for (int t = 0; t < RPO; ++t) {
+      // the rows' observation values go into the transposition buffer piece by piece as they are produced (a whole line of them in
+      // registers would cost 32 more)
+      auto row = [&](int t) __attribute__((always_inline)) {
         T fs[S], ob[O];
 #pragma unroll
         for (int j = 0; j < S; ++j) fs[j] = ring_get(j, l * RPO + t);
@@ -259,11 +266,18 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
           for (int q = 0; q < O; ++q) xp[(i * EM_LANES + (lane ^ i)) * VW + (t * O + q) % VW] = ob[q];
         }
+      };
+      if constexpr (NR <= 2) {  // small models: the rows of a line as straight-line code
+#pragma unroll
+        for (int t = 0; t < RPO; ++t) row(t);
+      } else {  // one row at a time: the rows' chains interleaved by the scheduler cost registers the ring needs
+#pragma unroll 1
+        for (int t = 0; t < RPO; ++t) row(t);
       }
       wave_sync();
       // element (row s, column o) of the window sits at ((env * rowlen + n_slot0 + s) * O + o); line l starts at s = l * RPO
-      emit_lines(obs_base + row_u * O + (int64_t)l * W, (int64_t)P * rowlen * O, lane_rows * (unsigned)O + (unsigned)(pi * VW), fast, s_lo,
-                 s_hi, [&](int h) { return l * RPO + (pi * VW + h) / O; });
+      emit_lines(std::integral_constant<int, NPL>{}, obs_base + row_u * O + (int64_t)l * WL, (int64_t)P * rowlen * O,
+                 lane_rows_o * (unsigned)O + (unsigned)(po * VW), fast, s_lo, s_hi, [&](int h) { return l * RPO + (po * VW + h) / O; });
     }
   };
 
