@@ -80,3 +80,34 @@ def test_env_major_mode_values_are_validated():
             _run(env, st, acts, bad)
     for ok in (0, 1, 2, 3):
         _run(env, st, acts, ok)
+
+
+@pytest.mark.filterwarnings("ignore:the reference's 1 . int")
+def test_register_ring_fuzz_against_lane_major():
+    """Random (model, dtype, solver, semantics, B, K, observations-only) draws: the register-ring form, forced on whatever the
+    batch size, holds the bits of the lane-major kernel."""
+    rng = np.random.default_rng(2026)
+    names = ["pmsm", "pendulum", "fluid_tank", "cartpole", "acrobot", "mass_spring_damper"]
+    done = 0
+    for it in range(60):
+        env_name = names[rng.integers(len(names))]
+        dtype = [torch.float32, torch.float64][rng.integers(2)]
+        if env_name == "pmsm" and dtype is torch.float64:
+            continue  # stays on the LDS-ring form (kernels_emr.hpp emr_supported)
+        solver = ["euler", "rk4", "tsit5"][rng.integers(3)]
+        B = int(rng.integers(1, 40)) * 64 + int(rng.integers(0, 64)) * int(rng.integers(0, 2))
+        K = int(rng.integers(1, 140))
+        A = 2 if env_name == "pmsm" else 1
+        if (B * K * A * (4 if dtype is torch.float32 else 8)) % 16:
+            continue
+        env, props, keep, spec = make_env(env_name, B, dtype, solver=solver)
+        env.sim_ahead_semantics = ["ahead", "step"][rng.integers(2)]
+        env.store_state_trajectory = bool(rng.integers(0, 4))
+        st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=1000 + it)
+        acts = torch.as_tensor(rng.uniform(-1, 1, (B, K, env.action_dim)).astype(NP_DTYPE[dtype]), device=env.device)
+        ring = _run(env, st, acts, 3)
+        env.traj_layout, env.launch_opts = "lane_major", None
+        lane = env.vmap_sim_ahead(to_state(env, st), acts, env.tau, env.tau)
+        _same(env, ring, lane)
+        done += 1
+    assert done >= 30
