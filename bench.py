@@ -441,7 +441,7 @@ def main():
 
     # set-up: the first calls create (and place) the pooled output sets of the trajectory path; with fewer than four warm-up
     # steps they are made here, outside warm-up and timed region alike
-    setup_steps = max(0, 4 - args.warmup) if args.path != "step" else 0
+    setup_steps = max(0, 6 - args.warmup) if args.path != "step" else 0
     for _ in range(setup_steps):
         state = one_step(state)
     for _ in range(args.warmup):

@@ -43,15 +43,16 @@ template <class M, bool AHEAD> constexpr int emr_ring_leaves() {
 // Steps per window. Two waves must share a SIMD (one wave alone leaves the VALU half idle: 9.9 ms for the headline launch with
 // 128-byte windows at one wave per SIMD, 7.7 ms with 64-byte windows at two), so a lane has 256 registers and the windows of
 // all ring leaves must fit next to the integration's own: 128-byte runs (whole lines, 32 registers per leaf) while the ring
-// stays within EXCENV_EMR_MAX_RING_REGS, else 64-byte runs (half lines, written 4 lanes x 16 bytes). PMSM in fp64 does not
-// fit either way (a double-precision integration next to 6 x 16 registers: > 100 spilled) and stays on the LDS-ring kernel.
+// stays within EXCENV_EMR_MAX_RING_REGS, else 64-byte runs (half lines, written 4 lanes x 16 bytes). PMSM in fp64 (5 ... 6 leaves
+// x 8 doubles next to a double-precision integration) fits since the torque leaf left the ring and the action line is loaded at
+// the crossing: two registers are spilled, reloaded only on the IEEE-division fallback path of the flush.
 #ifndef EXCENV_EMR_MAX_RING_REGS
 #define EXCENV_EMR_MAX_RING_REGS 128
 #endif
 template <class M, typename T, bool AHEAD> constexpr int emr_rows() {
   return (emr_ring_leaves<M, AHEAD>() * 32 <= EXCENV_EMR_MAX_RING_REGS ? 128 : 64) / (int)sizeof(T);
 }
-template <class M, typename T> constexpr bool emr_supported() { return !M::HAS_LUT && !(M::S > 4 && sizeof(T) == 8); }
+template <class M, typename T> constexpr bool emr_supported() { return !M::HAS_LUT; }  // the look-up model keeps the LDS-ring kernel
 
 // LDS bytes per wave: the transposition buffer (64 lanes x 128 bytes) and the action line slots (64 x 128 bytes)
 template <class M, typename T, bool AHEAD> constexpr size_t emr_lds_bytes() { return (size_t)EM_LANES * (128 + 128); }
@@ -281,10 +282,11 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     }
   };
 
-  // The next action line: prefetched a whole line ahead into 32 registers that stay live through the loop (PMSM: +5 ... 8 % over
-  // loading at the crossing, and its 64-byte windows leave the room), or loaded at the crossing, the SIMD's other waves covering
-  // the latency (the smaller models: those 32 registers are a third wave per SIMD; cart-pole 0.45 -> 0.50, pendulum 0.51 -> 0.54).
-  constexpr bool PREFETCH = M::IS_PMSM;
+  // The next action line: prefetched a whole line ahead into 32 registers that stay live through the loop (PMSM fp32: +5 ... 8 %
+  // over loading at the crossing, and its 64-byte windows leave the room), or loaded at the crossing, the SIMD's other waves
+  // covering the latency (the smaller models: those 32 registers are a third wave per SIMD; cart-pole 0.45 -> 0.50, pendulum
+  // 0.51 -> 0.54; PMSM fp64: they are what keeps the kernel from spilling).
+  constexpr bool PREFETCH = M::IS_PMSM && sizeof(T) == 4;
   T lineR[PREFETCH ? WL : 1];
   {
     T first[WL];

@@ -92,8 +92,6 @@ def test_register_ring_fuzz_against_lane_major():
     for it in range(60):
         env_name = names[rng.integers(len(names))]
         dtype = [torch.float32, torch.float64][rng.integers(2)]
-        if env_name == "pmsm" and dtype is torch.float64:
-            continue  # stays on the LDS-ring form (kernels_emr.hpp emr_supported)
         solver = ["euler", "rk4", "tsit5"][rng.integers(3)]
         B = int(rng.integers(1, 40)) * 64 + int(rng.integers(0, 64)) * int(rng.integers(0, 2))
         K = int(rng.integers(1, 140))
