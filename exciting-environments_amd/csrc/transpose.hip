@@ -69,8 +69,53 @@ __global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ in
   }
 }
 
+// Short input rows (N * sizeof(T) <= 2 KiB: the [K*A]-long action rows of a trajectory): a tile is TM WHOLE rows, i.e. one
+// contiguous chunk of the input — streamed in with 16-byte loads — and leaves as N runs of TM elements, 16 consecutive lanes per
+// run. The general kernel reads such rows as 128-byte pieces 800 bytes apart (3.2 TB/s for the actions of the headline launch).
+template <typename T, int TM>
+__global__ void __launch_bounds__(256) transpose_rows_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t M, int N) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* tile = reinterpret_cast<T*>(smem);  // [TM][N + 1]
+  const int LD = N + 1;
+  const int64_t m0 = (int64_t)blockIdx.x * TM;
+  const int tm = (int)((M - m0 < TM) ? (M - m0) : TM);  // a multiple of VW (host: M % VW == 0)
+  const int t = threadIdx.x;
+  const T* src = in + m0 * N;
+  const int nvec = tm * N / VW;  // N % VW == 0 (host)
+  using V = typename VecT<T, VW>::type;
+  for (int i = t; i < nvec; i += 256) {
+    const V v = *reinterpret_cast<const V*>(src + (int64_t)i * VW);
+    const T* e = reinterpret_cast<const T*>(&v);
+    const int r = (i * VW) / N, c = (i * VW) % N;  // a vector never straddles rows (N % VW == 0)
+#pragma unroll
+    for (int j = 0; j < VW; ++j) tile[r * LD + c + j] = e[j];
+  }
+  __syncthreads();
+  const int rv = tm / VW;  // 16-byte pieces per output run
+  for (int i = t; i < N * rv; i += 256) {
+    const int c = i / rv, r = (i % rv) * VW;
+    V v;
+    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) e[j] = tile[(r + j) * LD + c];
+    *reinterpret_cast<V*>(out + (int64_t)c * M + m0 + r) = v;
+  }
+}
+
 template <typename T> static int launch_t(int64_t M, int64_t N, const T* in, T* out, hipStream_t stream) {
   // short output rows (M small): 64 input columns x the whole row; otherwise 32 columns x up to ~500 rows
+  {
+    constexpr int VW = 16 / (int)sizeof(T);
+    constexpr int TMR = 64;
+    const bool al = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+    if (al && N * (int64_t)sizeof(T) <= 2048 && (N % VW) == 0 && (M % VW) == 0 && M >= 4096 &&
+        (N + 1) * TMR * (int64_t)sizeof(T) <= LDS_BUDGET && (M + TMR - 1) / TMR < ((int64_t)1 << 31)) {
+      const dim3 grid((unsigned)((M + TMR - 1) / TMR)), block(256);
+      hipLaunchKernelGGL((transpose_rows_kernel<T, TMR>), grid, block, (size_t)TMR * (N + 1) * sizeof(T), stream, in, out, M, (int)N);
+      return hipGetLastError() == hipSuccess ? EXCENV_OK : EXCENV_EHIP;
+    }
+  }
   const bool wide = (int64_t)M * 65 * (int64_t)sizeof(T) <= LDS_BUDGET;
   const int TN = wide ? 64 : 32;
   constexpr int VMAX = 16 / (int)sizeof(T);

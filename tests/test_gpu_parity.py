@@ -733,3 +733,25 @@ def test_state_structure_is_stable_through_step_and_sim_ahead_for_tsit5(env_name
     assert all(tuple(l.shape) == (B, K + 1) for l in tree_flatten(traj.additions.solver_state)[0])
     _, s2 = env.vmap_step(last, act)  # a state that came out of a trajectory steps on
     assert tree_structure(s2) == tree_structure(s0)
+
+
+@pytest.mark.parametrize("env_name,dtype,B,K", [("pmsm", torch.float32, 8192, 26), ("pmsm", torch.float64, 4100, 17),
+                                                ("pendulum", torch.float32, 8260, 24), ("cartpole", torch.float64, 6000, 256),
+                                                ("pendulum", torch.float32, 8192, 25)])
+def test_row_major_actions_of_large_batches_equal_lane_major_actions(env_name, dtype, B, K):
+    """Reference-shaped [B, K, A] actions with the default trajectories: the library transposes them through scratch memory —
+    batches >= 4096 with short rows made of whole 16-byte pieces take the row-block form of the transposition
+    (csrc/transpose.hip), the last case (K * A = 25 words) the general one. Same bits as lane-major actions."""
+    env, props, keep, spec = make_env(env_name, B, dtype)
+    st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=71)
+    acts = np.random.default_rng(72).uniform(-1, 1, (B, K, env.action_dim)).astype(NP_DTYPE[dtype])
+    a_row = torch.as_tensor(acts, device=env.device)
+    a_lane = env.new_actions_buffer(K)
+    a_lane.copy_(a_row)
+    assert a_row.is_contiguous() and not a_lane.is_contiguous()
+    o1, s1, l1 = env.vmap_sim_ahead(to_state(env, st), a_row, env.tau, env.tau)
+    o2, s2, l2 = env.vmap_sim_ahead(to_state(env, st), a_lane, env.tau, env.tau)
+    assert torch.equal(o1, o2)
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(s1.physical_state, n), getattr(s2.physical_state, n))
+        assert torch.equal(getattr(l1.physical_state, n), getattr(l2.physical_state, n))
