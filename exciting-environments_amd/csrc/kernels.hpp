@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
 #pragma unroll
     for (int q = 0; q < A; ++q) load_v<T, V>(a_blk + krow * ka.a_sk + q * ka.a_sc + a_lane, dst[q]);
   };
-  auto advance = [&](const T (&cur)[A][V], const T (&nxt)[A][V], int64_t k, int64_t k1) {
+  auto advance = [&](const T (&cur)[A][V], const T (&nxt)[A][V], int64_t k, int64_t k1) __attribute__((always_inline)) {
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       T ac[A], an[A];

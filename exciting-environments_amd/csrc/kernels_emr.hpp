@@ -49,8 +49,8 @@ template <class M, bool AHEAD> constexpr int emr_ring_leaves() {
 #ifndef EXCENV_EMR_MAX_RING_REGS
 #define EXCENV_EMR_MAX_RING_REGS 128
 #endif
-template <class M, typename T, bool AHEAD> constexpr int emr_rows() {
-  return (emr_ring_leaves<M, AHEAD>() * 32 <= EXCENV_EMR_MAX_RING_REGS ? 128 : 64) / (int)sizeof(T);
+template <class M, typename T, bool AHEAD> constexpr int emr_rows() {  // a double-precision integration needs twice the registers itself
+  return (emr_ring_leaves<M, AHEAD>() * 32 <= EXCENV_EMR_MAX_RING_REGS / ((int)sizeof(T) / 4) ? 128 : 64) / (int)sizeof(T);
 }
 template <class M, typename T> constexpr bool emr_supported() { return !M::HAS_LUT; }  // the look-up model keeps the LDS-ring kernel
 

@@ -449,3 +449,26 @@ def test_headline_loop_stays_inside_the_instruction_cache():
     # the C2 / C4 kernels (pendulum Euler fp32, mass-spring-damper Tsit5 fp64) are far below it
     small = [v[0] for k, v in spans.items() if ("Pendulum" in k or "MassSpringDamper" in k) and "sim_ahead_kernel" in k]
     assert small and max(small) <= 60 * 1024
+
+
+def test_trajectory_kernels_do_not_spill():
+    """Guard rail (tools/loop_code_size.py kernel_resources): a trajectory kernel that spills reloads its registers behind
+    `s_waitcnt vmcnt(0)`, i.e. behind every outstanding trajectory store (the register-ring kernel lost 0.6 of 7.7 ms to 18 spilled
+    registers; a non-inlined lambda costs a stack frame the same way). The headline kernels use no scratch memory at all; the
+    register-ring kernels at most a few bytes that only cold paths touch."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("loop_code_size", os.path.join(ROOT, "tools", "loop_code_size.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not (os.path.exists(mod.OBJDUMP) and os.path.exists(mod.READELF)):
+        pytest.skip("llvm-objdump / llvm-readelf not available")
+    res = mod.kernel_resources()
+    assert res[mod.HEADLINE]["scratch"] == 0 and res[mod.HEADLINE]["vgpr"] <= 256
+    ring = {k: v for k, v in res.items() if "sim_ahead_emr_kernel" in k}
+    assert len(ring) >= 60
+    worst = max(ring.items(), key=lambda kv: kv[1]["scratch"])
+    assert worst[1]["scratch"] <= 48, worst  # fp64 PMSM: one register pair, reloaded only on the IEEE-division fallback path
+    assert all(v["scratch"] == 0 for k, v in ring.items() if "PmsmIfEE" in k)
+    lean32 = {k: v for k, v in res.items() if "sim_ahead_kernel" in k and "IfEEf" in k and "PmsmSat" not in k}
+    assert lean32 and all(v["scratch"] == 0 for v in lean32.values()), [k for k, v in lean32.items() if v["scratch"]]

@@ -54,6 +54,36 @@ def loop_spans(lib=LIB):
     return out
 
 
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def kernel_resources(lib=LIB):
+    """{kernel symbol: {"scratch": private segment bytes per lane, "vgpr": count, "sgpr": count}} from the code objects' metadata
+    notes. A trajectory kernel that starts to spill reloads its registers behind `s_waitcnt vmcnt(0)`, i.e. behind every
+    outstanding trajectory store (kernels_emr.hpp: 7.7 -> 7.1 ms when the last spills went): worth failing the build for."""
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        so = os.path.join(td, "lib.so")
+        shutil.copy(lib, so)
+        subprocess.run([OBJDUMP, "--offloading", so], check=True, cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for elf in sorted(glob.glob(os.path.join(td, "lib.so.*amdgcn*"))):
+            notes = subprocess.run([READELF, "--notes", elf], check=True, capture_output=True, text=True).stdout
+            cur = {}
+            for line in notes.splitlines():
+                m = re.match(r"\s*-?\s*\.(name|private_segment_fixed_size|vgpr_count|sgpr_count):\s*(\S+)", line)
+                if not m:
+                    continue
+                k, v = m.group(1), m.group(2).strip("'\"")
+                if k == "name" and not v.startswith("_Z"):
+                    continue  # argument names
+                cur[k] = v
+                if all(x in cur for x in ("name", "private_segment_fixed_size", "vgpr_count", "sgpr_count")):
+                    out[cur["name"]] = {"scratch": int(cur["private_segment_fixed_size"]), "vgpr": int(cur["vgpr_count"]),
+                                        "sgpr": int(cur["sgpr_count"])}
+                    cur = {}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--limit", type=int, default=60 * 1024)
