@@ -52,7 +52,7 @@ static const EnvVTable* table_for(int env, const excenv_props_t* props, int* rc)
   return table(env);
 }
 
-static const excenv_launch_opts_t kDefaultOpts = {0, 0, 0, 0};
+static const excenv_launch_opts_t kDefaultOpts = {0, 0, 0, 0};  // envs_per_lane, env_major_mode, lds_pad_bytes, flags
 
 static int check_opts(const char* fn, const excenv_launch_opts_t*& o) {
   if (!o) o = &kDefaultOpts;
@@ -60,7 +60,7 @@ static int check_opts(const char* fn, const excenv_launch_opts_t*& o) {
   if (!(v == 0 || v == 1 || v == 2 || v == 4)) { set_error("%s: opts.envs_per_lane must be 0, 1, 2 or 4 (got %d)", fn, v); return EXCENV_EINVAL; }
   if (o->env_major_mode < 0 || o->env_major_mode > 3) { set_error("%s: opts.env_major_mode must be 0, 1, 2 or 3", fn); return EXCENV_EINVAL; }
   if (o->lds_pad_bytes < 0 || o->lds_pad_bytes > 150 * 1024) { set_error("%s: opts.lds_pad_bytes out of range", fn); return EXCENV_EINVAL; }
-  if (o->reserved != 0) { set_error("%s: opts.reserved must be 0", fn); return EXCENV_EINVAL; }
+  if ((o->flags & ~EXCENV_OPT_NO_FUSED_ACTIONS) != 0) { set_error("%s: opts.flags has unknown bits set (0x%x)", fn, (unsigned)o->flags); return EXCENV_EINVAL; }
   return EXCENV_OK;
 }
 
@@ -171,6 +171,19 @@ int64_t excenv_sim_ahead_workspace_bytes(int env, int dtype, int64_t B, int64_t 
   return bytes;
 }
 
+int excenv_sim_ahead_fuses_actions(int env, int solver, int dtype, int64_t B, int64_t K, const excenv_props_t* props,
+                                   int32_t n_control, int with_gym, int action_layout, int traj_layout, const void* actions,
+                                   const excenv_launch_opts_t* opts) {
+  if (check_common("excenv_sim_ahead_fuses_actions", env, solver, dtype, B) || !props) return 0;
+  if (check_opts("excenv_sim_ahead_fuses_actions", opts)) return 0;
+  int trc;
+  const EnvVTable* t = table_for(env, props, &trc);
+  if (!t) return 0;
+  return aem_applies(env, props->pmsm_lut != nullptr, props_batched(props, t->P, t->S, t->A) || n_control > 0 || with_gym != 0, t->A,
+                     dtype == EXCENV_F64 ? 8 : 4, B, K, solver, opts->envs_per_lane, action_layout, traj_layout, opts->flags, actions)
+             ? 1 : 0;
+}
+
 int excenv_transpose(int dtype, int64_t M, int64_t N, const void* in, void* out, void* stream) {
   if ((dtype != EXCENV_F32 && dtype != EXCENV_F64) || M < 0 || N < 0) { set_error("excenv_transpose: bad argument"); return EXCENV_EINVAL; }
   if ((!in || !out) && M * N > 0) { set_error("excenv_transpose: NULL argument"); return EXCENV_ENULL; }
@@ -209,13 +222,19 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
                                           t->O, (size_t)wbytes);
   const int64_t need = excenv_sim_ahead_workspace_bytes(env, dtype, B, K, substeps, nc, action_layout, traj_layout,
                                                         state_traj != nullptr);
-  const bool via_ws = !fused_em && !gym && workspace && need > 0 && workspace_bytes >= need && B > 0 &&
+  // row-major actions + lane-major trajectories: the trajectory kernel reads the actions itself (no workspace, no extra pass)
+  const bool fused_actions =
+      aem_applies(env, props->pmsm_lut != nullptr, props_batched(props, t->P, t->S, t->A) || nc > 0 || gym != nullptr, t->A,
+                  (size_t)wbytes, B, K, solver, opts->envs_per_lane, action_layout, traj_layout, opts->flags, actions) &&
+      aligned16(obs_traj);
+  const bool via_ws = !fused_em && !fused_actions && !gym && workspace && need > 0 && workspace_bytes >= need && B > 0 &&
                       (action_layout == EXCENV_LAYOUT_ENV_MAJOR || traj_layout == EXCENV_LAYOUT_ENV_MAJOR);
   const int em = !fused_em ? 1 : (opts->env_major_mode == 2 ? 3 : (opts->env_major_mode == 3 ? 4 : 2));
   if (!via_ws) {
     SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, actions, action_layout,
                obs_traj, state_traj, traj_layout, last_state, semantics, opts->envs_per_lane, opts->lds_pad_bytes, em, gym,
                (hipStream_t)stream};
+    sc.flags = opts->flags;
     return t->sim(sc);
   }
   // env-major buffers + workspace: transpose in, run the coalesced lane-major kernel, transpose out

@@ -380,10 +380,32 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
 // LUT_LDS (look-up models): the launch staged the tables in LDS (true) or the kernel gathers from global memory (false) —
 // a compile-time property so that each instantiation carries ONE copy of the look-up code (the saturated-PMSM loops are
 // the largest in the library and run out of the 64 KB instruction cache otherwise).
-template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false>
+//
+// AEM (row-major actions — the reference's plain actions[B][K][A] tensor — read by the lane-major kernel itself, no transposition
+// pass; lean instantiations with V * sizeof(T) == 16 only). Time is the contiguous axis of that array, so what a lane needs per
+// step (A values of each of ITS V environments) lies K * A elements apart from its neighbour's. Fetching it 16 bytes at a time
+// costs one 64-byte fabric read per piece (measured: TCC_EA_RDREQ == number of pieces, 7.4 ms for the headline launch); the L2
+// does not keep a line until the walk returns to it. So an environment's row is fetched in WINDOWS of AEM_NP pieces (64 bytes)
+// by AEM_NP ADJACENT LANES of one LDS-direct load (global_load_lds_dwordx4: lane t of instruction i loads piece t % NP of
+// environment-slot i * 64 / NP + t / NP and the hardware puts it at M0 + 16 t — the window of an environment is contiguous in
+// LDS as in memory, one 64-byte request per environment and window). Every wave owns V * NP blocks of 1 KiB (+ 16 bytes each:
+// bank skew for the readers) and fetches only the rows of its own lanes' environments: no barrier, every wave on its own.
+// Single-buffered: the window is re-filled right after the read of its last row (the row is read one solver step before it is
+// used, so the fill has a step to land; the counted s_waitcnt in front of the first read of a window leaves that step's
+// trajectory stores in flight).
+template <typename T, int V> constexpr bool aem_shape_ok() { return V * (int)sizeof(T) == 16; }
+#ifndef EXCENV_AEM_NP
+#define EXCENV_AEM_NP 4  // 16-byte pieces per window (64 bytes; V * NP KiB of LDS per wave)
+#endif
+constexpr int AEM_BLOCK_BYTES = 1024 + 16;  // one LDS-direct load instruction's 1 KiB + the bank skew
+template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return (size_t)(BLOCK / 64) * V * EXCENV_AEM_NP * AEM_BLOCK_BYTES; }
+
+template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false>
 __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
   static_assert(!(GENERAL && V > 1), "vectorised lanes share one uniform property set");
+  static_assert(!AEM || (!GENERAL && !M::HAS_LUT && aem_shape_ok<T, V>() && (16 / (int)sizeof(T)) % A == 0),
+                "row-major actions are fused into the widest lean instantiation only");
   const int64_t blk0 = (int64_t)blockIdx.x * (BLOCK * V);  // first env of this workgroup
   const unsigned lane_env = threadIdx.x * V;
   const int64_t i0 = blk0 + lane_env;
@@ -394,7 +416,8 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   c.lin_last = ka.K - 1;
   stage_lut<M, T>(c, ka.kp);
   if constexpr (M::HAS_LUT) c.lut_lds = LUT_LDS ? 1 : 0;  // == ka.kp.lut_lds (launch_sim_v picks the instantiation by it)
-  if (i0 >= ka.B) return;  // host guarantees B % V == 0
+  // host guarantees B % V == 0; AEM: B % (64 V) == 0 — a wave is whole or absent (its lanes also fetch for each other)
+  if (i0 >= ka.B) return;
 
   T st[V][S];
 #pragma unroll
@@ -526,9 +549,75 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   }
 
   T a0[A][V], a1[A][V];
-  auto load_action = [&](int64_t krow, T (&dst)[A][V]) {
+  // (k, sub): action row and sub-step of solver step n; (kn, subn): those of step n + 1
+  int64_t k = 0, kn = 0;
+  int32_t sub = 0, subn = 0;
+  // ---- AEM: the wave's action windows in LDS (see the comment above the kernel) ----
+  constexpr int VW = 16 / (int)sizeof(T);  // elements per 16-byte piece
+  constexpr int SP = AEM ? VW / A : 1;     // action rows per piece
+  constexpr int NP = EXCENV_AEM_NP;        // pieces per window
+  constexpr int RW = NP * SP;              // rows per window
+  constexpr int EPI = 64 / NP;             // environments (reader lanes) per load instruction
+  static_assert(64 % NP == 0, "a load instruction covers whole windows");
+  extern __shared__ __align__(16) unsigned char excenv_smem[];
+  const unsigned wave = threadIdx.x / 64u, lane64 = threadIdx.x % 64u;
+  const unsigned wave_off = AEM ? __builtin_amdgcn_readfirstlane(wave * (unsigned)(V * NP * AEM_BLOCK_BYTES)) : 0u;  // this wave's blocks
+  const unsigned wave_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)excenv_smem + wave_off;  // as an LDS address
+  // reader side: lane l's environment v sits in block (v, l / EPI) at window offset (l % EPI) * NP * 16
+  const unsigned rd_lane = (lane64 / EPI) * AEM_BLOCK_BYTES + (lane64 % EPI) * (NP * 16u);
+  // loader side: lane t serves reader lane slot t / NP of the instruction's EPI, piece t % NP
+  const unsigned ld_piece = lane64 % NP;
+  const uint64_t ld_lane_off = AEM ? ((uint64_t)(wave * 64u + lane64 / NP) * V) * (uint64_t)ka.a_sb : 0;  // elements, before (i, v)
+  const int64_t n_pieces = AEM ? (ka.K * A) / VW : 0;  // pieces per environment row (host: K * A % VW == 0)
+  constexpr int NSTORE = O + ((STATES != 0) ? S : 0);   // trajectory stores per saved row: issued between a fill and its first read
+  int64_t w_hi = -1;                                    // highest window requested so far (wave-uniform)
+  auto dma_window = [&](int64_t w) __attribute__((always_inline)) {
+    if constexpr (AEM) {
+      int64_t pc = w * NP + ld_piece;
+      pc = pc < n_pieces ? pc : n_pieces - 1;  // a short last window: the spare lanes fetch the last piece again (never read)
+      const T* lane_src = a_blk + ld_lane_off + pc * VW;
 #pragma unroll
-    for (int q = 0; q < A; ++q) load_v<T, V>(a_blk + krow * ka.a_sk + q * ka.a_sc + a_lane, dst[q]);
+      for (int v = 0; v < V; ++v) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          // Inline assembly, not __builtin_amdgcn_global_load_lds: the compiler treats an LDS-direct load as a FLAT access and puts
+          // `s_waitcnt vmcnt(0)` in front of every later LDS read — that would drain the trajectory stores once per step. Hidden
+          // from it, the only wait is the counted one in load_action below. (M0 = the LDS byte address of the block; the compiler
+          // itself never uses M0 in this kernel.)
+          const T* src = lane_src + (uint64_t)(i * EPI * V + v) * (uint64_t)ka.a_sb;
+          asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(wave_lds + (unsigned)(v * NP + i) * AEM_BLOCK_BYTES)
+                       : "memory");
+        }
+      }
+    }
+  };
+  auto load_action = [&](int64_t krow, T (&dst)[A][V]) __attribute__((always_inline)) {
+    if constexpr (AEM) {
+      const int64_t w = krow / RW;
+      const unsigned r = (unsigned)(krow % RW), off = (r / SP) * 16u + (r % SP) * (unsigned)(A * sizeof(T));
+      // first row of a window that was requested one row earlier: everything but the trajectory stores issued since must be back
+      // (vmcnt retires in issue order). Wave-uniform.
+      if (r == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE < 63 ? NSTORE : 63) : "memory");
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        T rr[A];
+        load_row<T, A>(reinterpret_cast<const T*>(excenv_smem + wave_off + (unsigned)(v * NP) * AEM_BLOCK_BYTES + rd_lane + off), rr);
+#pragma unroll
+        for (int q = 0; q < A; ++q) dst[q][v] = rr[q];
+      }
+      // last row of the window, requested for the last time (with sub-steps a row is requested once as the row after the current
+      // one and then once per further sub-step of its own action step; subn is the sub-step the requested row will serve): the
+      // window's LDS is dead once these reads have returned -> request the next window into it. w_hi: once per window, whatever
+      // the clamped tail of the trajectory repeats.
+      if (r == RW - 1 && subn == ka.substeps - 1 && w + 1 > w_hi && (w + 1) * NP < n_pieces) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_window(w + 1);
+        w_hi = w + 1;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < A; ++q) load_v<T, V>(a_blk + krow * ka.a_sk + q * ka.a_sc + a_lane, dst[q]);
+    }
   };
   auto advance = [&](const T (&cur)[A][V], const T (&nxt)[A][V], int64_t k, int64_t k1) __attribute__((always_inline)) {
 #pragma unroll
@@ -546,15 +635,17 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
       }
     }
   };
-  // (k, sub): action row and sub-step of solver step n; (kn, subn): those of step n + 1
-  int64_t k = 0, kn;
-  int32_t sub = 0, subn;
   auto next_index = [&]() {
     kn = k;
     subn = sub + 1;
     if (subn == ka.substeps) { subn = 0; kn = k + 1; }
   };
   const int64_t klast = ka.K - 1;
+  if constexpr (AEM) {  // the first window of every environment
+    dma_window(0);
+    w_hi = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once per trajectory (the initial state has arrived as well)
+  }
   load_action(0, a0);
   // look-up models keep the single-step loop: twice the (large) look-up code does not fit the instruction cache
   constexpr bool PINGPONG = !M::HAS_LUT && ((SOLVER == EXCENV_EULER) ? (EXCENV_PINGPONG & 1) : (EXCENV_PINGPONG & 2)) != 0;

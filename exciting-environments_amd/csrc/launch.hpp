@@ -53,7 +53,39 @@ struct SimCall {
                  // 4 = register-ring kernel whenever its preconditions hold (no batch-size heuristic)
   const excenv_traj_gym_t* gym;  // optional reward / terminated / truncated trajectories
   hipStream_t stream;
+  int flags = 0;  // excenv_launch_opts_t.flags
 };
+
+// Row-major actions [B][K][A] with lane-major trajectories — what a reference-shaped vmap_sim_ahead call with the library's
+// default outputs is: the widest lean instantiation reads them itself through a per-wave LDS piece ring (kernels.hpp, AEM)
+// instead of a transposition pass in front of the launch. Decided once per call (excenv_api.hip decides with the same function
+// whether a workspace transposition is needed at all). EXCENV_AEM=0 in the environment switches it off (A/B measurements).
+static inline bool aem_enabled() {
+  static const int on = [] { const char* e = std::getenv("EXCENV_AEM"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
+static inline int auto_envs_per_lane(int64_t B, int vmax);
+static inline bool aem_applies(int env_id, bool has_lut, bool general, int A, size_t elem, int64_t B, int64_t K, int solver,
+                               int vec_pref, int action_layout, int traj_layout, int flags, const void* actions) {
+  const int vmax = 16 / (int)elem;
+  if (!aem_enabled() || (flags & EXCENV_OPT_NO_FUSED_ACTIONS) || has_lut || general) return false;
+  if (action_layout != EXCENV_LAYOUT_ENV_MAJOR || traj_layout != EXCENV_LAYOUT_LANE_MAJOR) return false;
+  if (K < 1 || (vmax % A) != 0 || (K * A) % vmax != 0) return false;  // whole 16-byte pieces per row
+  if ((B % (64 * vmax)) != 0) return false;  // whole waves: the lanes of a wave fetch action windows for each other
+  if ((reinterpret_cast<uintptr_t>(actions) & 15u) != 0) return false;
+  if ((int64_t)EXCENV_BLOCK * vmax * K * A >= ((int64_t)1 << 32)) return false;             // 32-bit element offsets inside a workgroup
+  // only where the batch takes the widest form anyway (launch_sim picks the same way)
+  int want = vec_pref > 0 ? vec_pref : auto_envs_per_lane(B, vmax);
+  if (vec_pref == 0 && env_id == EXCENV_ACROBOT && solver != EXCENV_EULER && want > 2) want = 2;
+  return want == vmax;
+}
+static inline bool props_batched(const excenv_props_t* p, int P, int S, int A) {
+  bool b = false;
+  for (int j = 0; j < P; ++j) b |= p->static_params[j].per_env != nullptr;
+  for (int j = 0; j < S; ++j) b |= p->state_min[j].per_env != nullptr || p->state_max[j].per_env != nullptr;
+  for (int j = 0; j < A; ++j) b |= p->action_min[j].per_env != nullptr || p->action_max[j].per_env != nullptr;
+  return b;
+}
 
 // The fused env-major kernel applies when both layouts are env-major, substeps == 1, the caller did not opt out, no gym
 // trajectories are requested and the time tile fits LDS. Decided once per call (excenv_api.hip) and handed to launch_sim.
@@ -190,10 +222,12 @@ static bool fill_props(KProps<T, M>& kp, const excenv_props_t* p) {
   } while (0)
 
 // Dynamic LDS for the saturated model's tables: staged when they fit LDS (<= 150 KiB, leaving room for one workgroup).
-template <typename T, class M> static size_t lut_lds_bytes(KProps<T, M>& kp, size_t other) {
+// `other`: further dynamic LDS of the launch (returned with the tables' share); `static_bytes`: static LDS of the kernel itself
+// (step_kernel's dense observation staging) — it counts against the workgroup's limit but is not part of the dynamic size.
+template <typename T, class M> static size_t lut_lds_bytes(KProps<T, M>& kp, size_t other, size_t static_bytes = 0) {
   if constexpr (!M::HAS_LUT) return other;
   const size_t need = ((size_t)kp.lut_nd * kp.lut_nq * 8 + 2 * (size_t)(kp.lut_nd + kp.lut_nq)) * sizeof(T);  // tables, grids, cell-width reciprocals
-  if (kp.lut_tab && need + other <= 150 * 1024) {
+  if (kp.lut_tab && need + other + static_bytes <= 150 * 1024) {
     kp.lut_lds = 1;
     return need + other;
   }
@@ -297,7 +331,11 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
   }
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
-  const size_t step_lds = lut_lds_bytes<T, M>(ka.kp, 0);
+  // the DENSE observation path of step_kernel (kernels.hpp) stages BLOCK rows in static LDS: tables that would not fit next to
+  // it stay in global memory (L2) instead of failing the launch
+  constexpr int VWs = 16 / (int)sizeof(T);
+  const bool dense = !general && V == 1 && (M::O % VWs) == 0 && (M::O / VWs) > 1;
+  const size_t step_lds = lut_lds_bytes<T, M>(ka.kp, 0, dense ? sizeof(T) * BLOCK * M::O : 0);
 #define EXCENV_STEP_LAUNCH(SOLV, GEN, VV) EXCENV_LAUNCH_DYN((step_kernel<M, T, SOLV, GEN, VV>), grid, block, step_lds, sc.stream, ka)
 #define EXCENV_STEP_CASE(SOLV)                                                 \
   case SOLV:                                                                   \
@@ -318,12 +356,21 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
 }
 
 template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(const SimCall& sc_in, const SimArgs<T, M>& ka_in,
-                                                                                 bool general, int V) {
+                                                                                 bool general, int V, bool aem = false) {
   SimArgs<T, M> ka = ka_in;
   SimCall sc = sc_in;
   sc.lds_pad = (int)lut_lds_bytes<T, M>(ka.kp, (size_t)sc_in.lds_pad);
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
+  if constexpr (!M::HAS_LUT && (16 / (int)sizeof(T)) % M::A == 0) {
+    if (aem) {  // row-major actions through the per-wave LDS piece ring: V == 16 / sizeof(T) (aem_applies)
+      constexpr int VA = 16 / (int)sizeof(T);
+      const size_t lds = aem_lds_bytes<M, T, VA>() + (size_t)sc_in.lds_pad;
+      if (ka.straj[0] == nullptr) EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 0, false, true>), grid, block, lds, sc.stream, ka);
+      else EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 1, false, true>), grid, block, lds, sc.stream, ka);
+      return;
+    }
+  }
   // look-up models: one instantiation per place the tables live in (LDS when they fit, lut_lds_bytes above)
 #define EXCENV_SIM_LAUNCH(GEN, VV, ST)                                                                                          \
   do {                                                                                                                          \
@@ -506,7 +553,10 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
 #undef EXCENV_EM_CASE
     return check_launch("excenv_sim_ahead (env-major fused)");
   }
-  vec_ok &= (sc.action_layout != EXCENV_LAYOUT_ENV_MAJOR) && (sc.traj_layout != EXCENV_LAYOUT_ENV_MAJOR);
+  const bool aem = vec_ok && aligned16(ka.obs) &&
+                   aem_applies(M::ID, M::HAS_LUT, general, M::A, sizeof(T), sc.B, sc.K, sc.solver, sc.vec_pref, sc.action_layout,
+                               sc.traj_layout, sc.flags, ka.actions);
+  vec_ok &= (sc.action_layout != EXCENV_LAYOUT_ENV_MAJOR || aem) && (sc.traj_layout != EXCENV_LAYOUT_ENV_MAJOR);
   vec_ok &= aligned16(ka.actions) && aligned16(ka.obs);
   constexpr int VMAX = 16 / (int)sizeof(T);
   int V = 1;
@@ -526,6 +576,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     while (want > 1 && (sc.B % want) != 0) want >>= 1;
     V = want;
   }
+  if (aem && V != VMAX) { set_error("excenv_sim_ahead: internal error: fused row-major actions need %d environments per lane", VMAX); return EXCENV_EINVAL; }
   if (tiled_a || tiled_t) {  // a workgroup must not straddle tiles
     constexpr int VT = (int)(TILE / BLOCK);
     if (VT > VMAX || general || !vec_ok) {
@@ -551,8 +602,8 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   }
 #define EXCENV_SIM_CASE(SOLV)                                                         \
   case SOLV:                                                                          \
-    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(sc, ka, general, V);  \
-    else launch_sim_v<M, T, SOLV, false>(sc, ka, general, V);                         \
+    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(sc, ka, general, V, aem && V == VMAX);  \
+    else launch_sim_v<M, T, SOLV, false>(sc, ka, general, V, aem && V == VMAX);                         \
     break;
   switch (sc.solver) {
     EXCENV_SIM_CASE(EXCENV_EULER)

@@ -17,7 +17,7 @@ LAYOUT_ENV_MAJOR, LAYOUT_LANE_MAJOR, LAYOUT_TILED = 0, 1, 2
 TILE = 1024  # EXCENV_TILE
 SEM_STEP, SEM_AHEAD = 0, 1
 F32, F64 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _LIB_PATH = os.environ.get(  # EXCENV_HIP_LIB: A/B-test another build of the same library (tuning experiments)
     "EXCENV_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libexcenv_hip.so"))
@@ -47,7 +47,7 @@ class LaunchOpts(ctypes.Structure):
     """excenv_launch_opts_t: per-call launch shaping (None / NULL = defaults)."""
 
     _fields_ = [("envs_per_lane", ctypes.c_int32), ("env_major_mode", ctypes.c_int32), ("lds_pad_bytes", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("flags", ctypes.c_int32)]
 
 
 class TrajGym(ctypes.Structure):
@@ -100,6 +100,8 @@ def lib():
         l.excenv_sim_ahead_ws.argtypes = [ci, ci, ci, cl, cl, ctypes.c_int32, vp, vp, cd, cd, vp, vp, ci, vp, vp, ci, vp, ci, vp,
                                           vp, cl, vp, vp]
         l.excenv_stream_pattern.argtypes = [ctypes.c_int32, vp, vp, ctypes.c_int32, vp, vp, cl, cl, ctypes.c_int32, vp]
+        l.excenv_sim_ahead_fuses_actions.restype = ctypes.c_int
+        l.excenv_sim_ahead_fuses_actions.argtypes = [ci, ci, ci, cl, cl, vp, ctypes.c_int32, ci, ci, ci, vp, vp]
         if l.excenv_abi_version() != ABI_VERSION:
             raise ImportError("libexcenv_hip.so: ABI version mismatch")
         _lib = l
@@ -261,8 +263,19 @@ def sim_ahead_bytes(env_id: int, dtype: torch.dtype, with_state_traj: bool = Tru
     return int(lib().excenv_sim_ahead_bytes(env_id, dtype_id(dtype), int(with_state_traj)))
 
 
-def launch_opts(envs_per_lane: int = 0, env_major_mode: int = 0, lds_pad_bytes: int = 0) -> LaunchOpts:
-    return LaunchOpts(int(envs_per_lane), int(env_major_mode), int(lds_pad_bytes), 0)
+OPT_NO_FUSED_ACTIONS = 1  # EXCENV_OPT_NO_FUSED_ACTIONS
+
+
+def launch_opts(envs_per_lane: int = 0, env_major_mode: int = 0, lds_pad_bytes: int = 0, flags: int = 0) -> LaunchOpts:
+    return LaunchOpts(int(envs_per_lane), int(env_major_mode), int(lds_pad_bytes), int(flags))
+
+
+def sim_ahead_fuses_actions(env: int, solver: int, dtype: torch.dtype, B: int, K: int, props, n_control: int, with_gym: bool,
+                            action_layout: int, traj_layout: int, actions_ptr: int, opts: Optional[LaunchOpts]) -> bool:
+    """excenv_sim_ahead_fuses_actions: the trajectory kernel reads these row-major actions itself (no workspace needed)."""
+    return bool(lib().excenv_sim_ahead_fuses_actions(env, solver, dtype_id(dtype), B, K, ctypes.byref(props), n_control, int(with_gym),
+                                                     action_layout, traj_layout, actions_ptr,
+                                                     ctypes.byref(opts) if opts is not None else None))
 
 
 def _opts_ref(opts: Optional[LaunchOpts]):

@@ -134,6 +134,7 @@ class CoreEnvironment(ABC):
         self._placement_replaced = {}
         self._traj_bcast_cache = None
         self._ws_bytes_cache = None
+        self._fused_actions_cache = None
         self._last_out = None
         self._ctl_cache = None
         self._active_additions = None
@@ -1185,10 +1186,20 @@ class CoreEnvironment(ABC):
         traj_e = obs_e + (S * leaf_e if want_states else 0)
         opts = self.launch_opts
         ws_e = ws_bytes = 0
-        if a_layout == _native.LAYOUT_ENV_MAJOR:  # row-major actions: transposed through scratch by the library
+        if a_layout == _native.LAYOUT_ENV_MAJOR:
+            # row-major actions (a plain [B, K, A] tensor, what the reference's call hands over): large batches of broadcast-
+            # property environments read them inside the trajectory kernel (per-wave LDS piece ring); the rest
+            # is transposed through scratch by the library
             if not self.env_major_fused:
-                opts = _native.launch_opts(opts.envs_per_lane if opts else 0, 1, opts.lds_pad_bytes if opts else 0)
-            if self.env_major_workspace:
+                opts = _native.launch_opts(opts.envs_per_lane if opts else 0, 1, opts.lds_pad_bytes if opts else 0,
+                                           (opts.flags if opts else 0) | _native.OPT_NO_FUSED_ACTIONS)
+            fk = (B, K, sub, len(self.control_state), actions.data_ptr() % 16, id(props),
+                  None if opts is None else (opts.envs_per_lane, opts.flags))
+            if self._fused_actions_cache is None or self._fused_actions_cache[0] != fk:
+                self._fused_actions_cache = (fk, _native.sim_ahead_fuses_actions(
+                    self.ENV_ID, self._solver.id, dt, B, K, props, len(self.control_state), False, a_layout,
+                    _native.LAYOUT_LANE_MAJOR, actions.data_ptr(), opts))
+            if self.env_major_workspace and not self._fused_actions_cache[1]:
                 wk = (B, K, sub, len(self.control_state), want_states)
                 if self._ws_bytes_cache is None or self._ws_bytes_cache[0] != wk:
                     self._ws_bytes_cache = (wk, _native.sim_ahead_workspace_bytes(

@@ -267,7 +267,8 @@ def load_pmsm_lut(motor_variant, path=None) -> dict:
     """The motor's table file as the reference loads it (pmsm/motor_parameters.py:94,121: ``loadmat(<package>/LUT_<motor>_
     jax_grad.mat)``): a dict with i_d_vec, i_q_vec and the six (n_iq, n_id) tables. `path` is the file itself or a directory
     that holds it; without it the directory named by the environment variable EXCENV_PMSM_LUT_DIR and then
-    ``<this package>/data`` are searched (the repository keeps the reference's two files as fixtures under tests/golden/pmsm)."""
+    ``<this package>/data`` are searched — the package ships the reference's two table files there (data only; the same bytes as
+    the fixtures under tests/golden/pmsm), so ``PMSM.make(saturated=True, motor_variant=BRUSA)`` works out of the box."""
     import os
 
     from scipy.io import loadmat

@@ -33,8 +33,10 @@ extern "C" {
 #endif
 
 /* 4: v3 + excenv_random_state, excenv_update_ref_to, excenv_observe (additions only; every v3 signature is unchanged)
- * 5: v4 + excenv_stream_pattern (addition only) */
-#define EXCENV_ABI_VERSION 5
+ * 5: v4 + excenv_stream_pattern (addition only)
+ * 6: v5 + excenv_launch_opts_t.flags (the former `reserved` field; 0 keeps the old meaning); excenv_sim_ahead reads row-major
+ *    actions inside the lane-major trajectory kernel (no workspace needed for that combination) */
+#define EXCENV_ABI_VERSION 6
 
 /* Environment ids. Field orders follow the reference dataclasses. */
 typedef enum {
@@ -132,12 +134,15 @@ typedef struct {
  *                    trajectory arrays, else the LDS-ring form); 1: never (workspace + transposes, or generic strides);
  *                    2: fused, LDS-ring form only; 3: fused, register-ring form whenever its preconditions hold
  *   lds_pad_bytes  : extra dynamic LDS per sim_ahead workgroup (caps resident workgroups per CU; occupancy experiments)
- *   reserved       : must be 0 */
+ *   flags          : bit set of EXCENV_OPT_* (0 = defaults; unknown bits are an error)
+ *     EXCENV_OPT_NO_FUSED_ACTIONS : row-major actions with lane-major trajectories are transposed through the workspace
+ *                                   (or read with generic strides) instead of being read by the trajectory kernel itself */
+#define EXCENV_OPT_NO_FUSED_ACTIONS 1
 typedef struct {
   int32_t envs_per_lane;
   int32_t env_major_mode;
   int32_t lds_pad_bytes;
-  int32_t reserved;
+  int32_t flags; /* ABI <= 5: `reserved`, had to be 0 */
 } excenv_launch_opts_t;
 
 /* Optional reward / terminated / truncated trajectories of excenv_sim_ahead — what
@@ -221,6 +226,16 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
                         void* obs_traj, void* const* state_traj, int traj_layout, void* const* last_state,
                         int semantics, const excenv_traj_gym_t* gym, void* workspace, int64_t workspace_bytes,
                         const excenv_launch_opts_t* opts, void* stream);
+/* 1 when excenv_sim_ahead[_ws] with these arguments reads the row-major actions[B][K][A] (what the reference's
+ * vmap_sim_ahead is handed, core_env.py:571-616) inside the lane-major trajectory kernel itself — 64-byte windows of every
+ * environment's row through LDS, no transposition pass, no workspace — else 0 (then a workspace of
+ * excenv_sim_ahead_workspace_bytes lets the library transpose them first). Applies to broadcast properties without control
+ * columns / gym trajectories, the batch sizes that run V = 16 / sizeof(dtype) environments per lane with B % (64 V) == 0,
+ * K * A * sizeof(dtype) a multiple of 16 and 16-byte aligned actions; the state / output pointers must be 16-byte aligned as
+ * for every vectorised launch. */
+int excenv_sim_ahead_fuses_actions(int env, int solver, int dtype, int64_t B, int64_t K, const excenv_props_t* props,
+                                   int32_t n_control, int with_gym, int action_layout, int traj_layout, const void* actions,
+                                   const excenv_launch_opts_t* opts);
 /* out[n][m] = in[m][n] for a row-major M x N matrix of the given dtype (the conversion kernel used above). */
 int excenv_transpose(int dtype, int64_t M, int64_t N, const void* in, void* out, void* stream);
 
