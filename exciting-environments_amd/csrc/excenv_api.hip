@@ -8,6 +8,7 @@
 namespace excenv {
 
 static thread_local char g_err[512] = "";
+thread_local const char* g_last_launch = "";
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -92,6 +93,8 @@ extern "C" {
 int excenv_abi_version(void) { return EXCENV_ABI_VERSION; }
 
 const char* excenv_last_error(void) { return g_err; }
+
+const char* excenv_last_launch(void) { return g_last_launch; }
 
 int excenv_env_dims(int env, int32_t* S, int32_t* A, int32_t* O, int32_t* P) {
   const EnvVTable* t = table_public(env);
@@ -264,6 +267,7 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
   SimCall sc{solver, dtype, B, K, substeps, props, control, obs_stepsize, env_tau, state_in, k_actions, k_alayout,
              k_obs, k_straj_p, k_tlayout, last_state, semantics, opts->envs_per_lane, opts->lds_pad_bytes, 1, nullptr, st};
   if (int rc = t->sim(sc)) return rc;
+  g_last_launch = "transposition workspace + sim_ahead_kernel";
   if (traj_layout == EXCENV_LAYOUT_ENV_MAJOR) {
     if (int rc = launch_transpose(dtype, (N + 1) * OW, B, k_obs, obs_traj, st)) { set_error("excenv_sim_ahead: obs transpose failed"); return rc; }
     if (state_traj)

@@ -398,7 +398,11 @@ template <typename T, int V> constexpr bool aem_shape_ok() { return V * (int)siz
 #define EXCENV_AEM_NP 4  // 16-byte pieces per window (64 bytes; V * NP KiB of LDS per wave)
 #endif
 constexpr int AEM_BLOCK_BYTES = 1024 + 16;  // one LDS-direct load instruction's 1 KiB + the bank skew
-template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return (size_t)(BLOCK / 64) * V * EXCENV_AEM_NP * AEM_BLOCK_BYTES; }
+// Pieces per window. 64-byte windows everywhere (same-session sweep over nine workloads, tools/r4_aem_sweep.sh: 32-byte windows
+// cost 3 ... 30 % more: two fabric requests per 64 bytes) except acrobot, whose registers already cap it at two workgroups per
+// CU and which gains 6 % from the smaller LDS footprint.
+template <class M> constexpr int aem_np() { return M::ID == EXCENV_ACROBOT ? 2 : EXCENV_AEM_NP; }
+template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return (size_t)(BLOCK / 64) * V * aem_np<M>() * AEM_BLOCK_BYTES; }
 
 template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false>
 __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka) {
@@ -555,7 +559,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   // ---- AEM: the wave's action windows in LDS (see the comment above the kernel) ----
   constexpr int VW = 16 / (int)sizeof(T);  // elements per 16-byte piece
   constexpr int SP = AEM ? VW / A : 1;     // action rows per piece
-  constexpr int NP = EXCENV_AEM_NP;        // pieces per window
+  constexpr int NP = aem_np<M>();          // pieces per window
   constexpr int RW = NP * SP;              // rows per window
   constexpr int EPI = 64 / NP;             // environments (reader lanes) per load instruction
   static_assert(64 % NP == 0, "a load instruction covers whole windows");

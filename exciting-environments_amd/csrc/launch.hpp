@@ -14,6 +14,9 @@ void set_error(const char* fmt, ...);
 // Set by EXCENV_LAUNCH_DYN when raising a kernel's dynamic-LDS limit failed (the launch is then skipped and
 // check_launch reports the stored message instead of a generic launch error). Per thread, like the error string.
 static thread_local bool g_attr_failed = false;
+// Which form of the trajectory kernel the last excenv_sim_ahead[_ws] call of this thread enqueued (excenv_last_launch(): tests
+// assert that the path they mean to check is the one that ran; like the error string it is per thread and purely informational).
+extern thread_local const char* g_last_launch;  // defined in excenv_api.hip
 
 struct StepCall {
   int vec_pref;  // 0 auto, else forced envs per lane
@@ -526,6 +529,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
         default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
       }
 #undef EXCENV_EMR_CASE
+      g_last_launch = "sim_ahead_emr_kernel";
       return check_launch("excenv_sim_ahead (env-major fused, register ring)");
     }
   }
@@ -551,6 +555,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
       default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
     }
 #undef EXCENV_EM_CASE
+    g_last_launch = general ? "sim_ahead_em_kernel (general)" : "sim_ahead_em_kernel";
     return check_launch("excenv_sim_ahead (env-major fused)");
   }
   const bool aem = vec_ok && aligned16(ka.obs) &&
@@ -612,6 +617,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
   }
 #undef EXCENV_SIM_CASE
+  g_last_launch = general ? "sim_ahead_kernel (general)" : (aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? "sim_ahead_kernel (V=2)" : "sim_ahead_kernel (V=4)")));
   if (int rc = check_launch("excenv_sim_ahead")) return rc;
   if (split_control && !general) {
     ControlFillArgs<T, M> fa;

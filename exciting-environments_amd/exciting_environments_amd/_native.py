@@ -84,6 +84,7 @@ def lib():
             )
         l = ctypes.CDLL(_LIB_PATH)
         l.excenv_last_error.restype = ctypes.c_char_p
+        l.excenv_last_launch.restype = ctypes.c_char_p
         l.excenv_abi_version.restype = ctypes.c_int
         l.excenv_step_bytes.restype = ctypes.c_int64
         l.excenv_sim_ahead_bytes.restype = ctypes.c_int64
@@ -112,6 +113,11 @@ def _check(rc: int, what: str):
     if rc != 0:
         msg = lib().excenv_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def last_launch() -> str:
+    """excenv_last_launch(): which trajectory-kernel form the last sim_ahead call of this thread enqueued."""
+    return lib().excenv_last_launch().decode("utf-8", "replace")
 
 
 def dtype_id(dtype: torch.dtype) -> int:

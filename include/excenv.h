@@ -161,6 +161,11 @@ typedef struct {
 /* ---- introspection -------------------------------------------------------------------- */
 int excenv_abi_version(void);
 const char* excenv_last_error(void);
+/* Name of the trajectory-kernel form the last excenv_sim_ahead[_ws] call of this thread enqueued ("" before the first):
+ * "sim_ahead_kernel (V=1|V=2|V=4)", "sim_ahead_kernel (general)", "sim_ahead_kernel (row-major actions fused)",
+ * "sim_ahead_emr_kernel", "sim_ahead_em_kernel[ (general)]", "transposition workspace + sim_ahead_kernel". Informational
+ * (tests assert that the path they mean to check is the one that ran). */
+const char* excenv_last_launch(void);
 /* S = physical_state_dim, A = action_dim, O = observation width without control columns, P = #static params. */
 int excenv_env_dims(int env, int32_t* S, int32_t* A, int32_t* O, int32_t* P);
 /* Algorithmic HBM bytes per env-step: w*(S+A+S+O) for the step path,

@@ -92,7 +92,7 @@ def build(force: bool = False) -> str:
     """Compile liboracle.so with the committed Makefile (gcc)."""
     stale = not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("excenv_oracle.c", "oracle_body.inc", "Makefile")
+        for f in ("excenv_oracle.c", "oracle_body.inc", "oracle_rng.inc", "Makefile")
     )
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
@@ -311,3 +311,128 @@ def state_from_observation(env: str, obs0: np.ndarray, phys_norm: dict):
     else:
         normed = {name: obs0[..., j] for j, name in enumerate(f)}
     return [np.asarray(denormalize(normed[name], *phys_norm[name])) for name in f]
+
+
+# ---- jax.random restated (oracle_rng.inc): keys are int64 arrays [..., 2] holding uint32 words ---------------------------
+def _keys(keys) -> np.ndarray:
+    k = np.ascontiguousarray(np.asarray(keys, dtype=np.int64).reshape(-1, 2))
+    return k
+
+
+def threefry2x32(k0: int, k1: int, c0: int, c1: int):
+    out = (ctypes.c_uint32 * 2)()
+    lib().oracle_threefry2x32(ctypes.c_uint32(k0), ctypes.c_uint32(k1), ctypes.c_uint32(c0), ctypes.c_uint32(c1), out)
+    return int(out[0]), int(out[1])
+
+
+def prng_key(seed: int) -> np.ndarray:
+    """jax.random.PRNGKey(seed) key data: (seed >> 32, seed & 0xffffffff) (jax/_src/prng.py threefry_seed)."""
+    seed = int(seed)
+    return np.array([(seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF], dtype=np.int64)
+
+
+def split(keys, num: int = 2) -> np.ndarray:
+    """jax.random.split(key, num) for every key of a [..., 2] batch -> [..., num, 2]."""
+    lead = np.asarray(keys).shape[:-1]
+    k = _keys(keys)
+    out = np.empty((k.shape[0], num, 2), dtype=np.int64)
+    lib().oracle_split(ctypes.c_int64(k.shape[0]), k.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(num), out.ctypes.data_as(ctypes.c_void_p))
+    return out.reshape(lead + (num, 2))
+
+
+def random_bits(keys, m: int, bit_width: int = 32) -> np.ndarray:
+    lead = np.asarray(keys).shape[:-1]
+    k = _keys(keys)
+    out = np.empty((k.shape[0], m), dtype=np.int64)
+    lib().oracle_random_bits(ctypes.c_int64(k.shape[0]), k.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(m), ctypes.c_int32(bit_width),
+                             out.ctypes.data_as(ctypes.c_void_p))
+    return out.reshape(lead + (m,))
+
+
+def randint(keys, m: int, minval: int, maxval: int) -> np.ndarray:
+    lead = np.asarray(keys).shape[:-1]
+    k = _keys(keys)
+    out = np.empty((k.shape[0], m), dtype=np.int64)
+    lib().oracle_randint(ctypes.c_int64(k.shape[0]), k.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(m), ctypes.c_int32(minval),
+                         ctypes.c_int32(maxval), out.ctypes.data_as(ctypes.c_void_p))
+    return out.reshape(lead + (m,))
+
+
+def erfinv(y: float) -> float:
+    f = lib().oracle_erfinv
+    f.restype = ctypes.c_double
+    return float(f(ctypes.c_double(y)))
+
+
+def _sample(which, keys, dtype, m, lo, hi, width):
+    lead = np.asarray(keys).shape[:-1]
+    k = _keys(keys)
+    dtype = np.dtype(dtype)
+    out = np.empty((k.shape[0], width), dtype=dtype)
+    rc = lib().oracle_rng_sample(ctypes.c_int(which), ctypes.c_int(DTYPE_IDS[dtype]), ctypes.c_int64(k.shape[0]),
+                                 k.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(m), ctypes.c_double(lo), ctypes.c_double(hi),
+                                 out.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"oracle_rng_sample failed rc={rc}")
+    return out.reshape(lead + (width,))
+
+
+def uniform(keys, m: int, dtype=np.float32, minval=0.0, maxval=1.0) -> np.ndarray:
+    """jax.random.uniform(key, (m,), dtype, minval, maxval) -> [..., m]."""
+    return _sample(0, keys, dtype, m, minval, maxval, m)
+
+
+def normal(keys, dtype=np.float32) -> np.ndarray:
+    """jax.random.normal(key, (), dtype) -> [...]."""
+    return _sample(1, keys, dtype, 1, 0.0, 0.0, 1)[..., 0]
+
+
+def exponential(keys, dtype=np.float32) -> np.ndarray:
+    return _sample(2, keys, dtype, 1, 0.0, 0.0, 1)[..., 0]
+
+
+def gamma(keys, alpha: float, m: int, dtype=np.float32) -> np.ndarray:
+    """jax.random.gamma(key, alpha, (m,), dtype) -> [..., m]."""
+    return _sample(3, keys, dtype, m, alpha, 0.0, m)
+
+
+def ball2(keys, dtype=np.float32) -> np.ndarray:
+    """jax.random.ball(key, 2, dtype=dtype) -> [..., 2]."""
+    return _sample(4, keys, dtype, 1, 0.0, 0.0, 2)
+
+
+def random_state(env: str, keys, props: Props, dtype):
+    """vmap_init_state(keys) (core_env.py:649-662; init_state e.g. pendulum_env.py:270-276, PMSM pmsm_env.py:402-456):
+    (list of S state arrays [B], key leaf [B, 2])."""
+    dtype = np.dtype(dtype)
+    k = _keys(keys)
+    B = k.shape[0]
+    S = ENV_DIMS[ENV_IDS[env]][0]
+    st = [np.empty(B, dtype=dtype) for _ in range(S)]
+    leaf = np.empty((B, 2), dtype=np.int64)
+    rc = lib().oracle_random_state(ctypes.c_int(ENV_IDS[env]), ctypes.c_int(DTYPE_IDS[dtype]), ctypes.c_int64(B), ctypes.byref(props),
+                                   k.ctypes.data_as(ctypes.c_void_p), _ptr_array(st), leaf.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"oracle_random_state failed rc={rc}")
+    return st, leaf
+
+
+def update_ref(env: str, control_idx: Sequence[int], references: Sequence[np.ndarray], keys, hold, props: Props, dtype,
+               hold_min: int, hold_max: int):
+    """GymWrapper.update_ref over the batch (gym_wrapper.py:170-192), out of place: (new references, new keys [B, 2], new hold [B])."""
+    dtype = np.dtype(dtype)
+    k = _keys(keys)
+    B = k.shape[0]
+    hold = np.ascontiguousarray(np.asarray(hold, dtype=np.int64).reshape(B))
+    refs_in = [np.ascontiguousarray(r, dtype=dtype) for r in references]
+    refs_out = [np.empty(B, dtype=dtype) for _ in references]
+    k_out, h_out = np.empty((B, 2), dtype=np.int64), np.empty(B, dtype=np.int64)
+    idx = (ctypes.c_int32 * max(1, len(control_idx)))(*control_idx)
+    rc = lib().oracle_update_ref(ctypes.c_int(ENV_IDS[env]), ctypes.c_int(DTYPE_IDS[dtype]), ctypes.c_int64(B), ctypes.byref(props),
+                                 ctypes.c_int32(len(control_idx)), idx, _ptr_array(refs_in) if refs_in else None,
+                                 k.ctypes.data_as(ctypes.c_void_p), hold.ctypes.data_as(ctypes.c_void_p),
+                                 _ptr_array(refs_out) if refs_out else None, k_out.ctypes.data_as(ctypes.c_void_p),
+                                 h_out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(hold_min), ctypes.c_int32(hold_max))
+    if rc != 0:
+        raise RuntimeError(f"oracle_update_ref failed rc={rc}")
+    return refs_out, k_out, h_out

@@ -56,6 +56,75 @@ static const double TSIT5_B[6] = {0.09646076681806523, 0.01, 0.4798896504144996,
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 
+/* ---- jax.random, the part that does not depend on the working precision (the rest: oracle_rng.inc) ---------------------
+ * Threefry-2x32, 20 rounds: Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3" (SC'11), the rotation
+ * constants and key schedule of Random123's threefry2x32_R(20, ...) == jax/_src/prng.py threefry2x32 (apply_round, rotations
+ * [13, 15, 26, 6] / [17, 29, 16, 24], ks[2] = k0 ^ k1 ^ 0x1BD11BDA, five groups of four rounds with a key injection each). */
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+static void threefry2x32(const uint32_t key[2], uint32_t c0, uint32_t c1, uint32_t out[2]) {
+  static const int R[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+  const uint32_t ks[3] = {key[0], key[1], key[0] ^ key[1] ^ 0x1BD11BDAu};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+  for (int i = 0; i < 5; ++i) {
+    for (int j = 0; j < 4; ++j) {
+      x0 += x1;
+      x1 = rotl32(x1, R[i % 2][j]);
+      x1 ^= x0;
+    }
+    x0 += ks[(i + 1) % 3];
+    x1 += ks[(i + 2) % 3] + (uint32_t)(i + 1);
+  }
+  out[0] = x0;
+  out[1] = x1;
+}
+
+/* jax.random.split(key, n)[i] — threefry_split, partitionable form: the counter of element i of an iota over the output shape is
+ * the 64-bit index split into (high, low) words = (0, i); the new key is the pair of output words */
+static inline void rng_split_i(const uint32_t key[2], uint32_t i, uint32_t out[2]) { threefry2x32(key, 0u, i, out); }
+/* threefry_random_bits, partitionable form, element i of a shape with fewer than 2^32 elements: 32-bit draws are the XOR of the
+ * two output words, 64-bit draws are (word0 << 32) | word1 */
+static inline uint32_t rng_bits32(const uint32_t key[2], uint32_t i) {
+  uint32_t o[2];
+  threefry2x32(key, 0u, i, o);
+  return o[0] ^ o[1];
+}
+static inline uint64_t rng_bits64(const uint32_t key[2], uint32_t i) {
+  uint32_t o[2];
+  threefry2x32(key, 0u, i, o);
+  return ((uint64_t)o[0] << 32) | o[1];
+}
+/* jax.random.randint(key, (n,), minval, maxval)[i], default int32 dtype (random._randint): two 32-bit draws from the halves of
+ * split(key), span / multiplier arithmetic in uint32 with wrap-around */
+static int32_t rng_randint_i32(const uint32_t key[2], uint32_t i, int32_t minval, int32_t maxval) {
+  uint32_t k1[2], k2[2];
+  rng_split_i(key, 0, k1);
+  rng_split_i(key, 1, k2);
+  const uint32_t higher = rng_bits32(k1, i), lower = rng_bits32(k2, i);
+  uint32_t span = (uint32_t)maxval - (uint32_t)minval;
+  if (maxval <= minval) span = 1u;
+  uint32_t mult = (1u << 16) % span; /* 2 ** (nbits / 2) % span */
+  mult = (mult * mult) % span;       /* == 2 ** nbits % span */
+  const uint32_t off = ((higher % span) * mult + (lower % span)) % span;
+  return (int32_t)((uint32_t)minval + off);
+}
+/* erf_inv in double precision: Winitzki's closed-form start, then Newton on libm's erf (|y| < 0.5) or on erfc of the tail
+ * (no cancellation in 1 - |y|: exact for |y| >= 0.5). */
+static double erfinv_d(double y) {
+  if (y != y || y <= -1.0 || y >= 1.0) return (y == 1.0) ? INFINITY : ((y == -1.0) ? -INFINITY : NAN);
+  if (y == 0.0) return y;
+  const double ay = fabs(y), a = 0.147, two_over_sqrt_pi = 1.1283791670955126;
+  const double ln1 = log1p(-ay * ay), t = 2.0 / (3.141592653589793 * a) + 0.5 * ln1;
+  double x = sqrt(sqrt(t * t - ln1 / a) - t);
+  for (int it = 0; it < 8; ++it) {
+    const double fx = (ay < 0.5) ? (erf(x) - ay) : ((1.0 - ay) - erfc(x));
+    const double step = fx / (two_over_sqrt_pi * exp(-x * x));
+    x -= step;
+    if (fabs(step) <= 1e-17 * fabs(x)) break;
+  }
+  return (y < 0) ? -x : x;
+}
+
 /* ---- float instantiation ---- */
 #define REAL float
 #define FN(x) CAT(x, _f32)
@@ -66,7 +135,10 @@ static const double TSIT5_B[6] = {0.09646076681806523, 0.01, 0.4798896504144996,
 #define R_FMOD fmodf
 #define R_FMA fmaf
 #define R_ABS fabsf
+#define ORACLE_REAL_IS_FLOAT 1
 #include "oracle_body.inc"
+#include "oracle_rng.inc"
+#undef ORACLE_REAL_IS_FLOAT
 #undef REAL
 #undef FN
 #undef R_SIN
@@ -88,6 +160,7 @@ static const double TSIT5_B[6] = {0.09646076681806523, 0.01, 0.4798896504144996,
 #define R_FMA fma
 #define R_ABS fabs
 #include "oracle_body.inc"
+#include "oracle_rng.inc"
 #undef REAL
 #undef FN
 
@@ -183,4 +256,76 @@ int oracle_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
              : oracle_sim_ahead_f64(&ENVS[env], solver, B, K, substeps, props, control, obs_stepsize, env_tau,
                                     state_in, actions, action_layout, obs_traj, state_traj, traj_layout,
                                     last_state, semantics);
+}
+
+/* ---- jax.random restated (oracle_rng.inc): exported for the tests -------------------------------------------------------- */
+void oracle_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t* out) {
+  const uint32_t key[2] = {k0, k1};
+  threefry2x32(key, c0, c1, out);
+}
+
+/* keys [n][2] (uint32 words held in int64, like the product's key tensors) -> out [n][num][2] = jax.random.split(key, num) */
+void oracle_split(int64_t n, const int64_t* keys, int32_t num, int64_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t key[2] = {(uint32_t)keys[2 * i], (uint32_t)keys[2 * i + 1]};
+    for (int32_t j = 0; j < num; ++j) {
+      uint32_t o[2];
+      rng_split_i(key, (uint32_t)j, o);
+      out[(i * num + j) * 2] = (int64_t)o[0];
+      out[(i * num + j) * 2 + 1] = (int64_t)o[1];
+    }
+  }
+}
+
+/* out [n][m] = jax.random.bits(key, (m,)) with 32-bit (uint32 in int64) or 64-bit (bit pattern in int64) words */
+void oracle_random_bits(int64_t n, const int64_t* keys, int32_t m, int32_t bit_width, int64_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t key[2] = {(uint32_t)keys[2 * i], (uint32_t)keys[2 * i + 1]};
+    for (int32_t j = 0; j < m; ++j)
+      out[i * m + j] = (bit_width == 64) ? (int64_t)rng_bits64(key, (uint32_t)j) : (int64_t)rng_bits32(key, (uint32_t)j);
+  }
+}
+
+/* out [n][m] = jax.random.randint(key, (m,), minval, maxval), int32 form */
+void oracle_randint(int64_t n, const int64_t* keys, int32_t m, int32_t minval, int32_t maxval, int64_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t key[2] = {(uint32_t)keys[2 * i], (uint32_t)keys[2 * i + 1]};
+    for (int32_t j = 0; j < m; ++j) out[i * m + j] = (int64_t)rng_randint_i32(key, (uint32_t)j, minval, maxval);
+  }
+}
+
+double oracle_erfinv(double y) { return erfinv_d(y); }
+
+/* which: 0 uniform(key, (m,), lo, hi) -> [n][m]; 1 normal(key, ()) -> [n]; 2 exponential(key, ()) -> [n];
+ * 3 gamma(key, lo, (m,)) -> [n][m]; 4 ball(key, 2) -> [n][2] */
+int oracle_rng_sample(int which, int dtype, int64_t n, const int64_t* keys, int32_t m, double lo, double hi, void* out) {
+  if (which < 0 || which > 4 || (dtype != EXCENV_F32 && dtype != EXCENV_F64) || n < 0 || !keys || !out) return EXCENV_EINVAL;
+  if (dtype == EXCENV_F32) oracle_rng_sample_f32(which, n, keys, m, lo, hi, (float*)out);
+  else oracle_rng_sample_f64(which, n, keys, m, lo, hi, (double*)out);
+  return EXCENV_OK;
+}
+
+/* host-pointer twin of excenv_random_state */
+int oracle_random_state(int env, int dtype, int64_t B, const excenv_props_t* props, const int64_t* keys, void* const* state_out,
+                        int64_t* key_leaf) {
+  int rc = check_common(env, 0, dtype, B);
+  if (rc) return rc;
+  if (!props || !keys || !state_out || !key_leaf) return EXCENV_ENULL;
+  return dtype == EXCENV_F32 ? oracle_random_state_f32(&ENVS[env], B, props, keys, state_out, key_leaf)
+                             : oracle_random_state_f64(&ENVS[env], B, props, keys, state_out, key_leaf);
+}
+
+/* host-pointer twin of excenv_update_ref_to */
+int oracle_update_ref(int env, int dtype, int64_t B, const excenv_props_t* props, int32_t n_control, const int32_t* control_idx,
+                      const void* const* reference_in, const int64_t* keys_in, const int64_t* hold_in, void* const* reference_out,
+                      int64_t* keys_out, int64_t* hold_out, int32_t hold_min, int32_t hold_max) {
+  int rc = check_common(env, 0, dtype, B);
+  if (rc) return rc;
+  if (n_control < 0 || n_control > EXCENV_MAX_CONTROL) return EXCENV_EINVAL;
+  if (!props || !keys_in || !hold_in || !keys_out || !hold_out || (n_control > 0 && (!control_idx || !reference_in || !reference_out)))
+    return EXCENV_ENULL;
+  return dtype == EXCENV_F32 ? oracle_update_ref_f32(&ENVS[env], B, props, n_control, control_idx, reference_in, keys_in, hold_in,
+                                                     reference_out, keys_out, hold_out, hold_min, hold_max)
+                             : oracle_update_ref_f64(&ENVS[env], B, props, n_control, control_idx, reference_in, keys_in, hold_in,
+                                                     reference_out, keys_out, hold_out, hold_min, hold_max);
 }

@@ -109,3 +109,76 @@ def test_register_ring_fuzz_against_lane_major():
         _same(env, ring, lane)
         done += 1
     assert done >= 30
+
+
+# ---- the register-ring form against the reference's fixtures and the oracle DIRECTLY (not only against other kernels) --------
+@pytest.mark.parametrize("env_name", ["pendulum", "mass_spring_damper", "cartpole", "acrobot", "fluid_tank", "pmsm"])
+def test_fixture_sim_ahead_fp64_through_the_register_ring(env_name, golden):
+    """The whole reference fixture (10 000 steps; PMSM 1 000) in ONE launch of the register-ring kernel (forced: 64 environments
+    would take the LDS-ring form otherwise), reference-shaped row-major arrays, at the reference's own tolerance
+    (tests/envs/<env>/test_<env>.py: allclose(rtol 1e-16 | 1e-8, atol 1e-8))."""
+    from conftest import golden_rtol
+
+    g = golden[env_name]
+    B = 64
+    env, props, keep, spec = make_env(env_name, B, torch.float64)
+    env.sim_ahead_semantics = "step"
+    env.traj_layout = "env_major"
+    env.launch_opts = _native.launch_opts(env_major_mode=3)
+    obs0 = torch.as_tensor(np.repeat(g["observations"][:1], B, axis=0), device=env.device)
+    state = env.vmap_generate_state_from_observation(obs0)
+    acts = torch.as_tensor(np.repeat(g["actions"][None], B, axis=0), device=env.device)
+    obs, states, last = env.vmap_sim_ahead(state, acts, env.tau, env.tau)
+    assert _native.last_launch() == "sim_ahead_emr_kernel"
+    got = obs.cpu().numpy()
+    assert obs.is_contiguous() and got.shape == (B,) + g["observations"].shape
+    assert np.allclose(got[0][1:], g["observations"][1:], rtol=golden_rtol(env_name), atol=1e-8)
+    assert np.allclose(got[B - 1][1:], g["observations"][1:], rtol=golden_rtol(env_name), atol=1e-8)
+    assert np.array_equal(got, np.repeat(got[:1], B, axis=0))
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(last.physical_state, n), getattr(states.physical_state, n)[:, -1])
+
+
+@pytest.mark.parametrize("obs_only", [False, True])
+@pytest.mark.parametrize("semantics", ["step", "ahead"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_register_ring_matches_the_oracle_at_65536_environments(dtype, semantics, obs_only):
+    """PMSM, default options at a batch the heuristic gives to the register-ring kernel: observations, state trajectories and the
+    last state of three slices of the batch (first, last and a middle one that straddles waves) against the oracle's trajectory
+    from the same inputs, at the tolerances of test_vmap_sim_ahead_matches_oracle."""
+    import oracle
+    from helpers import ANGLE_STATES, circ_close, max_err
+
+    B, K = 65536, 64
+    env, props, keep, spec = make_env("pmsm", B, dtype)
+    env.sim_ahead_semantics = semantics
+    env.traj_layout = "env_major"
+    env.store_state_trajectory = not obs_only
+    st = random_state("pmsm", B, NP_DTYPE[dtype], spec, seed=47)
+    acts_np = np.random.default_rng(48).uniform(-1, 1, (B, K, 2)).astype(NP_DTYPE[dtype])
+    obs, states, last = env.vmap_sim_ahead(to_state(env, st), torch.as_tensor(acts_np, device=env.device), env.tau, env.tau)
+    assert _native.last_launch() == "sim_ahead_emr_kernel" and obs.is_contiguous()
+    sem = oracle.SEM_STEP if semantics == "step" else oracle.SEM_AHEAD
+    rtol, atol = (1e-5, 1e-5) if dtype is torch.float32 else (1e-9, 1e-9)
+    n = 1024
+    for sl in (slice(0, n), slice(B - n, B), slice(B // 2 - 37, B // 2 - 37 + n)):
+        sp, sk = oracle.make_props("pmsm", spec["params"], spec["phys_norm"], spec["act_norm"], NP_DTYPE[dtype], n)
+        o_ref, s_ref, l_ref = oracle.sim_ahead("pmsm", "euler", [s[sl] for s in st], acts_np[sl], sp, spec["tau"], semantics=sem)
+        got = obs[sl].cpu().numpy()
+        assert np.allclose(got, o_ref, rtol=rtol, atol=atol), max_err(got, o_ref)
+        for j, name in enumerate(env.STATE_FIELDS):
+            gl = getattr(last.physical_state, name)[sl].cpu().numpy()
+            scale = max(1.0, float(np.nanmax(np.abs(s_ref[j]))))
+            if states is not None:
+                gs = getattr(states.physical_state, name)[sl].cpu().numpy()
+                assert np.array_equal(gs[:, -1], gl)
+                if j in ANGLE_STATES["pmsm"]:
+                    assert circ_close(gs[..., None], s_ref[j][..., None], [0], rtol, atol * scale, period=2 * np.pi), name
+                else:
+                    assert np.allclose(gs, s_ref[j], rtol=rtol, atol=atol * scale), (name, max_err(gs, s_ref[j]))
+            else:
+                ref_last = l_ref[j]
+                if j in ANGLE_STATES["pmsm"]:
+                    assert circ_close(gl[:, None, None], np.asarray(ref_last)[:, None, None], [0], rtol, atol * scale, period=2 * np.pi), name
+                else:
+                    assert np.allclose(gl, ref_last, rtol=rtol, atol=atol * scale), name

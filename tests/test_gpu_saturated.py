@@ -190,6 +190,41 @@ def test_reference_motor_tables_step_and_sim_ahead_match_oracle(motor, solver, d
     assert np.isfinite(o_ref).all()
     assert np.allclose(obs.cpu().numpy(), o_ref, rtol=tol, atol=tol), float(np.abs(obs.cpu().numpy() - o_ref).max())
     assert np.allclose(new.physical_state.torque.cpu().numpy(), s_ref[5], rtol=tol, atol=tol * pn["torque"][1])
+    # ---- (A) the arithmetic itself, free of amplification: ONE step from states along the oracle's own trajectory ----------
+    # Where kernel and oracle separate was isolated in round 4 (tools/f3_divergence.py): one step from identical
+    # states gives bit-identical epsilon, i_d, i_q, torque in every environment, both motors, Euler and Tsit5 — cell search,
+    # bilinear blend, closed-form 2x2 inverse, invariant divisions and RK stage sums are the oracle's operations in the oracle's
+    # order. The ONLY difference is the clipped voltage that goes into the dead-time buffer: sin / cos of the Park rotation come
+    # from the device routines instead of libm (absolute <= 1e-15 of full scale in fp64). Everything a trajectory shows later is
+    # that last-place difference amplified by the machine (x 4 ... x 10^4 per step at these operating points, measured on the
+    # oracle itself), so the trajectory-level assertions below can only be loose; THIS one is exact.
+    eps_w = np.finfo(NP_DTYPE[dtype]).eps
+    o_tr, s_tr, _ = oracle.sim_ahead("pmsm", solver, st, acts, props, spec["tau"], semantics=oracle.SEM_STEP)
+    exact_leaves = ("epsilon", "i_d", "i_q", "torque", "omega_el")
+    rows = sorted(set(range(0, K, max(1, K // 8))) | {K - 1})
+    for r in rows:
+        st_r = [np.ascontiguousarray(x[:, r]) for x in s_tr]
+        fin = np.all([np.isfinite(x) for x in st_r], axis=0) & np.all([np.isfinite(x[:, r + 1]) for x in s_tr], axis=0)
+        assert fin.mean() > 0.9
+        env.sim_ahead_semantics = "step"
+        _, new = env.vmap_step(to_state(env, st_r), torch.as_tensor(acts[:, r], device=env.device))
+        for j, n in enumerate(env.STATE_FIELDS):
+            got, want = getattr(new.physical_state, n).cpu().numpy()[fin], s_tr[j][fin, r + 1]
+            if n in exact_leaves:
+                assert np.array_equal(got, want), (r, n, float(np.abs(got - want).max()))
+            else:  # u_d_buffer / u_q_buffer: device sin / cos in the rotation of the clipped voltage
+                assert np.abs(got - want).max() <= 16 * eps_w * pn[n][1], (r, n, float(np.abs(got - want).max()))
+        # the reference-structured launch, one action row from the same states (row 1 is post-processed: wrapped angle, torque)
+        env.sim_ahead_semantics = "ahead"
+        o1, s1, _l1 = env.vmap_sim_ahead(to_state(env, st_r), torch.as_tensor(acts[:, r:r + 1], device=env.device), env.tau, env.tau)
+        _o, s1_ref, _ = oracle.sim_ahead("pmsm", solver, st_r, acts[:, r:r + 1], props, spec["tau"], semantics=oracle.SEM_AHEAD)
+        for j, n in enumerate(env.STATE_FIELDS):
+            got, want = getattr(s1.physical_state, n).cpu().numpy()[fin, 1], s1_ref[j][fin, 1]
+            if n in exact_leaves:
+                assert np.array_equal(got, want), ("ahead", r, n, float(np.abs(got - want).max()))
+            else:
+                assert np.abs(got - want).max() <= 16 * eps_w * pn[n][1], ("ahead", r, n)
+    # ---- (B) whole trajectories ------------------------------------------------------------------------------------------
     for sem, osem in (("step", oracle.SEM_STEP), ("ahead", oracle.SEM_AHEAD)):
         env.sim_ahead_semantics = sem
         a_dev = env.new_actions_buffer(K)
@@ -197,24 +232,24 @@ def test_reference_motor_tables_step_and_sim_ahead_match_oracle(motor, solver, d
         o, s, l = env.vmap_sim_ahead(to_state(env, st), a_dev, env.tau, env.tau)
         o_ref, s_ref, l_ref = oracle.sim_ahead("pmsm", solver, st, acts, props, spec["tau"], semantics=osem)
         assert np.isfinite(o_ref).all()
-        # fp64 pins the arithmetic over the whole horizon. In fp32 these machines are violently sensitive (currents slew by
-        # ~100 A per step, the field is only piecewise smooth across table cells): the oracle's OWN fp32 and fp64 runs differ by
-        # up to 6e-2 (BRUSA) / 0.8 (SEW) within ten Tsit5 steps. The fp32 kernel is therefore held to the accuracy of the
-        # literal fp32 restatement: per saved row, its distance to the fp64 oracle stays within a small multiple of the
-        # fp32 oracle's distance to the fp64 oracle.
         err = np.abs(o.cpu().numpy() - o_ref)
         if dtype == torch.float64:
-            # no wider type to compare with: the natural amplification is measured by moving every input by one ulp
+            # fixed bound on the horizon where it still means something: three saved rows (measured <= 6e-11, SEW Tsit5; the
+            # oracle against itself from inputs one ulp away is at 5.5e-11 there and at 1e-6 by row 9)
+            assert err[:, :4].max() <= 1e-9, (sem, err[:, :4].max(axis=(0, 2)).tolist())
+            # beyond it: not worse than the machine's own amplification of a one-ulp change of the inputs
             o_pert = oracle.sim_ahead("pmsm", solver, [np.nextafter(x, np.inf) for x in st], acts, props, spec["tau"], semantics=osem)[0]
             nat = np.abs(o_pert - o_ref).max(axis=(0, 2))
             got = err.max(axis=(0, 2))
-            assert got[1] <= 1e-10 and np.all(got <= 16 * nat + 1e-10), (sem, got.tolist(), nat.tolist())
+            assert np.all(got <= 16 * nat + 1e-9), (sem, got.tolist(), nat.tolist())
         else:
+            # fp32: no fixed bound means anything here — one Tsit5 step of the SEW machine turns a last-place difference of the
+            # clipped voltage (6e-8) into 1e-2 of full scale (its c = 1 stage already sees the voltage clipped in this very
+            # step). Rows are held against the distance between the oracle's own fp32 and fp64 runs; the arithmetic is pinned
+            # exactly by (A).
             o64 = oracle.sim_ahead("pmsm", solver, [x.astype(np.float64) for x in st], acts.astype(np.float64), props64,
                                    spec["tau"], semantics=osem)[0]
             nat = np.abs(o_ref.astype(np.float64) - o64).max(axis=(0, 2))            # per row: fp32 oracle vs fp64 oracle
             got = np.abs(o.cpu().numpy().astype(np.float64) - o64).max(axis=(0, 2))  # per row: fp32 kernel vs fp64 oracle
             assert np.all(got <= 4 * nat + tol), (sem, got.tolist(), nat.tolist())
-        if dtype == torch.float64:  # the first saved rows of the state leaves, before the amplification sets in
-            assert np.allclose(s.physical_state.i_q.cpu().numpy()[:, :3], s_ref[4][:, :3], rtol=tol, atol=tol * pn["i_q"][1])
         assert torch.equal(l.physical_state.i_d, s.physical_state.i_d[:, -1])
