@@ -444,6 +444,13 @@ def main():
     setup_steps = max(0, 6 - args.warmup) if args.path != "step" else 0
     for _ in range(setup_steps):
         state = one_step(state)
+    # the pooled output sets are compared by the times of their real launches and a clearly slower one is replaced (core_env.py,
+    # "large trajectory outputs"): step until that is over, so that no placement search falls into the timed region
+    settle_steps = 0
+    while args.path != "step" and not getattr(env, "trajectory_placement_settled", True) and settle_steps < 24:
+        state = one_step(state)
+        torch.cuda.synchronize()
+        settle_steps += 1
     for _ in range(args.warmup):
         state = one_step(state)
     if gatherer is not None:
@@ -558,7 +565,8 @@ def main():
                 "backend": (dist.get_backend() if dist.is_initialized() else None),
                 "collective": (gatherer.collective if gatherer is not None else None),
                 "gathered_slice_matches_local": gather_ok,
-                "outputs_finite": finite, "setup_steps": setup_steps,
+                "outputs_finite": finite, "setup_steps": setup_steps, "placement_settle_steps": settle_steps,
+                "pooled_set_steady_ms": [None if t.steady_ms is None else round(t.steady_ms, 4) for t in getattr(env, "_traj_sets", [])],
                 "output_buffers": (("library-pooled output sets: a set is written again once nothing refers to it (the plain "
                                     "functional API, core_env.py trajectory sets); sets made this run: "
                                     f"{len(getattr(env, '_traj_sets', []))}" if getattr(env, "trajectory_pool", False)

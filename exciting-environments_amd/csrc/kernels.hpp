@@ -373,7 +373,8 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
 // later (Euler) or in the last RK stage of step n (c_i == 1 stages see action k+1) — its s_waitcnt therefore sits after a
 // compute phase and never has to drain the trajectory stores issued in between (vmcnt counts loads and stores in order).
 //
-// STATES: the state trajectories are written (1), not written (0), or decided by ka.straj[0] at run time (-1, GENERAL only).
+// STATES: the state trajectories are written (1), not written (0), or decided by ka.straj[0] at run time (GENERAL only: -1 with
+// the gym outputs' code, -2 without it).
 // It is a compile-time property on the vectorised instantiations because s_waitcnt vmcnt counts loads and stores in issue
 // order: with the state stores behind a run-time branch the compiler must assume the shorter path, and the wait for the
 // prefetched action row then also waits for the first seven stores of the row just written.
@@ -407,17 +408,30 @@ template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return 
 template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false>
 __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
-  static_assert(!(GENERAL && V > 1), "vectorised lanes share one uniform property set");
+  // GENERAL with V = 2 (round 4): every environment of a lane carries its own property set (a second Ctx in registers), so that
+  // per-environment property arrays and control columns keep 8-byte accesses and 512-byte rows per wave at large batches (one
+  // environment per lane: 0.57 of the roof whatever the instantiation, two: 0.7). Only without the gym outputs (STATES == -2:
+  // their code is compiled out; with it the save-row code of two environments is not inlined any more and the property sets
+  // end up in scratch memory) and not for the look-up models (registers).
+  static_assert(!(GENERAL && (V > 2 || (V == 2 && (M::HAS_LUT || STATES != -2)))), "per-environment property sets: at most two environments per lane");
+  static_assert(GENERAL == (STATES < 0), "STATES -1 / -2 (general, with / without the gym outputs' code) and 0 / 1 (lean)");
+  constexpr int NC = GENERAL ? V : 1;  // property sets per lane
+  constexpr bool GYM = GENERAL && STATES == -1;
   static_assert(!AEM || (!GENERAL && !M::HAS_LUT && aem_shape_ok<T, V>() && (16 / (int)sizeof(T)) % A == 0),
                 "row-major actions are fused into the widest lean instantiation only");
   const int64_t blk0 = (int64_t)blockIdx.x * (BLOCK * V);  // first env of this workgroup
   const unsigned lane_env = threadIdx.x * V;
   const int64_t i0 = blk0 + lane_env;
-  Ctx<T, M> c;
-  load_ctx<GENERAL>(c, ka.kp, (i0 < ka.B) ? i0 : 0, ka.dt, ka.env_tau, ka.adv_coef);
-  c.lin_stop = ka.lin_stop;
-  c.lin_div = T(ka.K - 1);
-  c.lin_last = ka.K - 1;
+  Ctx<T, M> cs[NC];
+#pragma unroll
+  for (int v = 0; v < NC; ++v) {
+    load_ctx<GENERAL>(cs[v], ka.kp, (i0 + v < ka.B) ? i0 + v : 0, ka.dt, ka.env_tau, ka.adv_coef);
+    cs[v].lin_stop = ka.lin_stop;
+    cs[v].lin_div = T(ka.K - 1);
+    cs[v].lin_last = ka.K - 1;
+  }
+  Ctx<T, M>& c = cs[0];  // what is the same for every environment of the lane (dead time, look-up tables: V == 1 there)
+#define EXCENV_CX(v) cs[GENERAL ? (v) : 0]
   stage_lut<M, T>(c, ka.kp);
   if constexpr (M::HAS_LUT) c.lut_lds = LUT_LDS ? 1 : 0;  // == ka.kp.lut_lds (launch_sim_v picks the instantiation by it)
   // host guarantees B % V == 0; AEM: B % (64 V) == 0 — a wave is whole or absent (its lanes also fetch for each other)
@@ -450,22 +464,25 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   }
 
   // reference-tracking columns: constant along the trajectory, loaded and normalised once (static register indices)
-  T rref[EXCENV_MAX_CONTROL], cref[EXCENV_MAX_CONTROL];
+  T rref[NC][EXCENV_MAX_CONTROL], cref[NC][EXCENV_MAX_CONTROL];
   if constexpr (GENERAL) {
 #pragma unroll
-    for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
-      rref[j] = T(0);
-      cref[j] = T(0);
-      if (j < ka.n_control) {
-        const int f = ka.control_idx[j];
-        T lo = c.smin[0], hi = c.smax[0];
+    for (int v = 0; v < NC; ++v) {
 #pragma unroll
-        for (int q = 1; q < S; ++q) {
-          lo = (f == q) ? c.smin[q] : lo;
-          hi = (f == q) ? c.smax[q] : hi;
+      for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+        rref[v][j] = T(0);
+        cref[v][j] = T(0);
+        if (j < ka.n_control) {
+          const int f = ka.control_idx[j];
+          T lo = cs[v].smin[0], hi = cs[v].smax[0];
+#pragma unroll
+          for (int q = 1; q < S; ++q) {
+            lo = (f == q) ? cs[v].smin[q] : lo;
+            hi = (f == q) ? cs[v].smax[q] : hi;
+          }
+          rref[v][j] = ka.reference[j][i0 + v];
+          cref[v][j] = normalize(rref[v][j], lo, hi);
         }
-        rref[j] = ka.reference[j][i0];
-        cref[j] = normalize(rref[j], lo, hi);
       }
     }
   }
@@ -488,7 +505,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
       for (int j = 0; j < S; ++j) sv[v][j] = st[v][j];
       if constexpr (AHEAD) {
         if constexpr (M::HAS_LUT) M::post_q(sv[v], c, memo[v]);
-        else M::post(sv[v], c);
+        else M::post(sv[v], EXCENV_CX(v));
         if constexpr (M::IS_PMSM) {  // pmsm_env.py:785-791
           if (deadtime_on) {
             sv[v][0] = aux[v].prev_clip[0];  // row 0: still the initial buffer (prev_clip starts as it)
@@ -502,7 +519,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
     }
     T ob[V][O];
 #pragma unroll
-    for (int v = 0; v < V; ++v) M::observe(sv[v], c, ob[v]);
+    for (int v = 0; v < V; ++v) M::observe(sv[v], EXCENV_CX(v), ob[v]);
     T* orow = o_blk + n * ka.o_sk;
 #pragma unroll
     for (int q = 0; q < O; ++q) {
@@ -513,8 +530,14 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
     }
     if constexpr (GENERAL) {
 #pragma unroll
-      for (int j = 0; j < EXCENV_MAX_CONTROL; ++j)
-        if (j < ka.n_control) orow[(O + j) * ka.o_sc + o_lane] = cref[j];
+      for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+        if (j < ka.n_control) {
+          T tmp[V];
+#pragma unroll
+          for (int v = 0; v < V; ++v) tmp[v] = cref[v][j];
+          store_v<T, V>(orow + (O + j) * ka.o_sc + o_lane, tmp);
+        }
+      }
     }
     if (with_states) {
 #pragma unroll
@@ -525,14 +548,14 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
         store_stream<T, V>(ka.straj[j] + s_blk + n * ka.s_sk + s_lane, tmp);
       }
     }
-    if constexpr (GENERAL) {  // core_env.py:490-531: truncated on every row, reward / terminated on rows 1..N
+    if constexpr (GYM) {  // core_env.py:490-531: truncated on every row, reward / terminated on rows 1..N (V == 1 here)
       if (ka.truncated != nullptr) {
         const int64_t e = i0;
         uint8_t* tr = ka.truncated + e * ka.t_sb + n * ka.t_sk;
         const bool tail = n > 0;
         T* rw = tail ? ka.reward + e * ka.g_sb + (n - 1) * ka.g_sk : nullptr;
         uint8_t* te = tail ? ka.terminated + e * ka.g_sb + (n - 1) * ka.g_sk : nullptr;
-        gym_outputs<M, T>(sv[0], ob[0], c, ka.n_control, ka.control_idx, rref, rw, te, tr, ka.t_sc);
+        gym_outputs<M, T>(sv[0], ob[0], c, ka.n_control, ka.control_idx, rref[0], rw, te, tr, ka.t_sc);
       }
     }
   };
@@ -633,9 +656,9 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
         an[q] = nxt[q][v];
       }
       if constexpr (AHEAD) {
-        env_advance_raw<M, SOLVER>(st[v], ac, an, k, k1, c, aux[v], M::HAS_LUT ? &memo[v] : nullptr);
+        env_advance_raw<M, SOLVER>(st[v], ac, an, k, k1, EXCENV_CX(v), aux[v], M::HAS_LUT ? &memo[v] : nullptr);
       } else {
-        env_step<M, SOLVER>(st[v], ac, c, M::HAS_LUT ? &memo[v] : nullptr);
+        env_step<M, SOLVER>(st[v], ac, EXCENV_CX(v), M::HAS_LUT ? &memo[v] : nullptr);
       }
     }
   };
@@ -694,6 +717,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
     }
   }
   publish_last(sv);
+#undef EXCENV_CX
 }
 
 // ---- reference-tracking observation columns of a trajectory (control_state; e.g. pendulum_env.py:311-329) --------------

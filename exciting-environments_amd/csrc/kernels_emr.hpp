@@ -9,9 +9,8 @@
 // written with a wave-uniform dynamic index (s_set_gpr_idx_on + v_mov) — so a window of a leaf is one aligned run per
 // environment, LDS holds no history, and two to three waves fit a SIMD.
 //   * UNIFORM PHASE. A run of env e's leaf row starts where (e * (N + 1) + n) % W == 0. Lanes of a wave take environments P
-//     apart, P = the period of that phase in e (a power of two <= W; the host computes it together with the same period of the
-//     action rows' line phase and passes the larger one): all 64 environments of a wave cross their run boundaries at the same
-//     steps, every ring index and every branch of the flush is wave-uniform.
+//     apart, P = the period of that phase in e (a power of two <= W, computed by the host): all 64 environments of a wave cross
+//     their run boundaries at the same steps, every ring index and every branch of the flush is wave-uniform.
 //   * FLUSH, once per W steps (plus head and tail): per leaf the NPC = W * sizeof(T) / 16 sixteen-byte pieces of a lane's run go
 //     through an LDS buffer (64 runs) in which each group of NPC lanes transposes its NPC x NPC pieces, so that a store
 //     instruction's adjacent lanes write the adjacent pieces of ONE environment's run: 64 lanes x 16 bytes = 64 / NPC whole runs
@@ -19,8 +18,9 @@
 //     at flush time (same device function on the same saved state as every other kernel: same bits) and leave the same way.
 //     Head / tail windows and ragged waves use the same code with a slot range; pieces cut by the range fall back to element
 //     stores.
-//   * ACTIONS. As in the LDS-ring kernel every 128-byte line is fetched once and parked in a per-lane LDS slot when the walk
-//     crosses into it; with the uniform phase the crossing is wave-uniform.
+//   * ACTIONS (round 4). 64-byte windows of every environment's row, fetched by four adjacent lanes of one LDS-direct load
+//     (one 64-byte request per environment and window; the scheme of sim_ahead_kernel's AEM instantiations): no registers, no
+//     line phase. Rows that are not made of whole 16-byte pieces take the LDS-ring kernel.
 // One wave per workgroup (LDS accesses of a wave execute in order: compiler fences only).
 #pragma once
 #include <type_traits>
@@ -53,12 +53,31 @@ template <class M, typename T, bool AHEAD> constexpr int emr_rows() {  // a doub
   return (emr_ring_leaves<M, AHEAD>() * 32 <= EXCENV_EMR_MAX_RING_REGS / ((int)sizeof(T) / 4) ? 128 : 64) / (int)sizeof(T);
 }
 template <class M, typename T> constexpr bool emr_supported() { return !M::HAS_LUT; }  // the look-up model keeps the LDS-ring kernel
+// LONG leaves (round 4 experiment, off by default). PMSM fp32's five ring leaves only fit as 64-byte windows, and half-line runs
+// cost more per byte than whole lines (tools/microbench/scatter_runs.hip: 3.2 against 5.3 TB/s), so a leaf may take windows twice
+// as long: EXCENV_EMR_LONG = 1: i_d, i_q (2 x 32 instead of 2 x 16 registers) and with them the torque recomputed from them and
+// the constant omega_el — four of seven leaves as whole 128-byte lines; = 2: the constant leaf alone (no register). Same-session
+// A/B on the headline launch, four runs each (gpurun_out/ab, round 4): 0: 6.39 ... 6.46 ms, 1: 6.46 ... 6.57 (256 registers),
+// 2: 6.47 ... 6.53 — the stores' run length is not what bounds this kernel (one dependent chain per wave at two
+// waves per SIMD). Bit-identical results in all three settings (tests/test_gpu_env_major_ring.py passes with each).
+#ifndef EXCENV_EMR_LONG
+#define EXCENV_EMR_LONG 0
+#endif
+template <class M, typename T, bool AHEAD> constexpr bool emr_has_long() { return EXCENV_EMR_LONG && M::IS_PMSM && AHEAD && sizeof(T) == 4; }
+template <class M, typename T, bool AHEAD> constexpr bool emr_is_long(int j) {  // EXCENV_EMR_LONG == 2: the constant leaf alone
+  return emr_has_long<M, T, AHEAD>() && j >= (EXCENV_EMR_LONG == 2 ? 6 : 3) && j <= 6;
+}
+template <class M, typename T, bool AHEAD> constexpr int emr_rows_long() { return emr_rows<M, T, AHEAD>() * (emr_has_long<M, T, AHEAD>() ? 2 : 1); }
 
-// LDS bytes per wave: the transposition buffer (64 lanes x 128 bytes) and the action line slots (64 x 128 bytes)
-template <class M, typename T, bool AHEAD> constexpr size_t emr_lds_bytes() { return (size_t)EM_LANES * (128 + 128); }
+// LDS bytes per wave: the transposition buffer (64 lanes x 128 bytes) and the action windows (EMR_ANP load instructions' blocks)
+constexpr int EMR_ANP = 4;  // 16-byte pieces per action window (64 bytes, fetched by 4 adjacent lanes of one LDS-direct load)
+template <class M, typename T, bool AHEAD> constexpr size_t emr_lds_bytes() { return (size_t)EM_LANES * 128 + (size_t)EMR_ANP * AEM_BLOCK_BYTES; }
 
 #ifndef EXCENV_EMR_DEBUG
 #define EXCENV_EMR_DEBUG 0  // experiments only (results are wrong): 1 never walk to the next action line, 2 no flush, 4 flush without global stores
+#endif
+#ifndef EXCENV_EMR_ROW_UNROLL
+#define EXCENV_EMR_ROW_UNROLL 1  // observation rows evaluated together at flush time (models with more than two ring leaves)
 #endif
 #ifndef EXCENV_EMR_NT
 #define EXCENV_EMR_NT 1  // whole-run stores of the flush are non-temporal (plain stores: 10 ... 11 ms instead of 7 for the headline launch)
@@ -79,10 +98,13 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   constexpr int NLO = W / RPO;              // observation lines per window and environment
   static_assert(WL % O == 0 && W % RPO == 0, "the observation rows of a window must be whole 128-byte lines");
   static_assert(WL % A == 0 && VW % A == 0, "an action row must not straddle a 16-byte piece");
+  constexpr int W2 = emr_rows_long<M, T, AHEAD>();  // steps per window of the long leaves (== W when there are none)
+  constexpr int NPC2 = W2 / VW;
   using Vec = typename EmrVec<T, W>::type;
+  using VecL = typename EmrVec<T, W2>::type;
   extern __shared__ __align__(16) unsigned char excenv_emr_smem[];
   T* const xp = reinterpret_cast<T*>(excenv_emr_smem);  // [NPC pieces][64 lanes]: piece p of lane l at lane position l ^ p (both directions conflict-free)
-  T* const slot_a = xp + EM_LANES * WL;                 // [8 pieces][64 lanes]: the action line each lane is in
+  T* const slot_a = xp + EM_LANES * WL;                 // EMR_ANP blocks of AEM_BLOCK_BYTES: the action window of every lane's environment
 
   const int lane = threadIdx.x;
   const int P = (int)ka.a_wg;
@@ -112,50 +134,69 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   const int64_t rowlen = N + 1;
   // wave-uniform window phase: slot of row n in the ring = (ph + n) % W (leaf and observation bases are 128-byte aligned, host)
   const int ph = (int)(((int64_t)r * (rowlen % W)) % W);
+  const int ph2 = (int)(((int64_t)r * (rowlen % W2)) % W2);  // the long leaves' windows; ph2 % W == ph
 
-  // ---- actions: line store with a wave-uniform phase ----
-  const int64_t off128 = (int64_t)(((uintptr_t)ka.actions & 127u) / sizeof(T));
-  const int64_t n_act = ka.B * ka.K * A;
-  const int64_t row0 = off128 + (active ? env : env0) * ka.K * A;  // this lane's action row 0 (element offset from the boundary)
-  const int pha = (int)((off128 + (int64_t)r * ((ka.K * A) % WL)) % WL);  // == row0 % WL for every lane
-  const int64_t line0 = row0 - pha;                                  // this lane's first line
-  auto load_line = [&](int64_t li, T (&dst)[WL]) {  // line number li of the lane's walk into registers, no wait
+  // ---- actions: 64-byte windows of every environment's row by LDS-direct loads (round 4; the scheme of sim_ahead_kernel's AEM
+  // instantiations, kernels.hpp). Lane t of load instruction i fetches piece t % ANP of the window of the environment that lane
+  // i * 64 / ANP + t / ANP integrates: ANP adjacent lanes = one 64-byte request per environment and window, landing contiguously
+  // in the instruction's 1 KiB block (+16 bytes of bank skew per block for the readers). Rows are 16-byte aligned (host:
+  // K * A * sizeof(T) % 16 == 0), so no line phase is involved and the lane spacing P follows from the trajectory rows alone.
+  // Round 3 walked 128-byte lines per lane (8 x 16-byte loads of ONE lane per line: FETCH_SIZE 1.5 x the action bytes) and
+  // held the next line in 32 registers.
+  constexpr int ANP = EMR_ANP, SP = VW / A, ARW = ANP * SP, AEPI = EM_LANES / ANP;
+  const unsigned act_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)excenv_emr_smem + (unsigned)(EM_LANES * WL * sizeof(T));
+  const unsigned rd_lane = (unsigned)(lane / AEPI) * AEM_BLOCK_BYTES + (unsigned)(lane % AEPI) * (ANP * 16u);
+  const int n_pieces = (int)((ka.K * A) / VW);
+  int w_hi = 0;  // highest window requested (wave-uniform)
+  auto dma_window = [&](int w) __attribute__((always_inline)) {
+    int pc = w * ANP + lane % ANP;
+    pc = pc < n_pieces ? pc : n_pieces - 1;  // a short last window: the spare lanes fetch the last piece again (never read)
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      int64_t p = line0 + li * WL + VW * i - off128;  // element index into ka.actions
-      p = (p < 0) ? 0 : p;
-      p = (p + VW > n_act) ? n_act - VW : p;
-      T v[VW];
-      load_v<T, VW>(ka.actions + p, v);
-#pragma unroll
-      for (int h = 0; h < VW; ++h) dst[i * VW + h] = v[h];
+    for (int i = 0; i < ANP; ++i) {
+      int64_t e = env0 + (int64_t)P * (i * AEPI + lane / ANP);
+      e = (e < ka.B) ? e : env0;  // ragged wave: the loaders of absent environments fetch lane 0's row (never read)
+      const T* src = ka.actions + e * ka.K * A + (int64_t)pc * VW;
+      // inline assembly: see kernels.hpp (the builtin makes the compiler drain vmcnt in front of every LDS read). M0 = LDS
+      // address of the block; written and consumed inside this one statement (the ring's s_set_gpr_idx sequences also use M0).
+      asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(act_lds + (unsigned)i * AEM_BLOCK_BYTES) : "memory");
     }
   };
-  auto park_line = [&](const T (&src)[WL]) {
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      T v[VW];
-#pragma unroll
-      for (int h = 0; h < VW; ++h) v[h] = src[i * VW + h];
-      store_v<T, VW>(slot_a + (i * EM_LANES + lane) * VW, v);
-    }
-  };
-  auto read_row = [&](int idx, T (&a)[A]) {  // row at element idx of the parked line
-    load_row<T, A>(slot_a + ((idx / VW) * EM_LANES + lane) * VW + idx % VW, a);
+  auto read_row = [&](int krow, T (&a)[A]) __attribute__((always_inline)) {  // row krow of this lane's environment out of its window
+    const unsigned r = (unsigned)krow % ARW, off = (r / SP) * 16u + (r % SP) * (unsigned)(A * sizeof(T));
+    load_row<T, A>(reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(slot_a) + rd_lane + off), a);
   };
 
   if (env0 >= ka.B) return;  // no barrier is ever used: a wave without environments may leave
   constexpr int CL = emr_const_leaf<M>();           // this leaf's saved value is st[CL] at every step
   constexpr int DL = emr_derived_leaf<M, AHEAD>();  // this leaf's saved value is a function of other saved leaves
   constexpr int NR = emr_ring_leaves<M, AHEAD>();
-  auto ridx = [](int j) constexpr { return j - ((CL >= 0 && j > CL) ? 1 : 0) - ((DL >= 0 && j > DL) ? 1 : 0); };
-  Vec ring[NR];
+  auto is_long = [](int j) constexpr { return emr_is_long<M, T, AHEAD>(j); };
+  auto in_ring = [](int j) constexpr { return j != CL && j != DL; };
+  // index of leaf j among the ring leaves of its class (short / long windows)
+  auto ridx = [is_long, in_ring](int j) constexpr {
+    int n = 0;
+    for (int q = 0; q < j; ++q) n += (in_ring(q) && is_long(q) == is_long(j)) ? 1 : 0;
+    return n;
+  };
+  constexpr int NRL = is_long(3) ? 2 : 0;  // i_d, i_q (torque is derived from them, omega_el is constant)
+  constexpr int NRS = NR - NRL;
+  Vec ring[NRS > 0 ? NRS : 1];
+  VecL ringL[NRL > 0 ? NRL : 1];
 #pragma unroll
-  for (int j = 0; j < NR; ++j) ring[j] = (Vec)(T(0));
-  auto ring_get = [&](int j, int s_) __attribute__((always_inline)) -> T {  // j: compile-time constant at every call
+  for (int j = 0; j < NRS; ++j) ring[j] = (Vec)(T(0));
+#pragma unroll
+  for (int j = 0; j < NRL; ++j) ringL[j] = (VecL)(T(0));
+  // value of leaf j at slot s_ of ITS class's window (j: compile-time constant at every call)
+  auto ring_get = [&](int j, int s_) __attribute__((always_inline)) -> T {
     if (j == CL) return st[CL >= 0 ? CL : 0];
     if constexpr (M::IS_PMSM) {
-      if (j == DL) return M::torque(ring[ridx(3)][s_], ring[ridx(4)][s_], c);
+      if (j == DL) {
+        if constexpr (NRL > 0) return M::torque(ringL[ridx(3)][s_], ringL[ridx(4)][s_], c);
+        else return M::torque(ring[ridx(3)][s_], ring[ridx(4)][s_], c);
+      }
+    }
+    if constexpr (NRL > 0) {
+      if (is_long(j)) return ringL[ridx(j)][s_];
     }
     return ring[ridx(j)][s_];
   };
@@ -166,9 +207,10 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   // One run per environment through the transposition buffer: put_pieces writes this lane's run, emit_lines stores this lane's
   // piece of the runs of its group's environments (groups of NP lanes, NP pieces per run); `slot_of(h)`: ring slot that element
   // h of this lane's piece belongs to.
-  auto put_pieces = [&](auto&& elem) __attribute__((always_inline)) {  // elem(h): element h of this lane's run, produced piece by piece
+  auto put_pieces = [&](auto np_tag, auto&& elem) __attribute__((always_inline)) {  // elem(h): element h of this lane's run, produced piece by piece
+    constexpr int NPP = decltype(np_tag)::value;
 #pragma unroll
-    for (int i = 0; i < NPC; ++i) {
+    for (int i = 0; i < NPP; ++i) {
       T v[VW];
 #pragma unroll
       for (int h = 0; h < VW; ++h) v[h] = elem(i * VW + h);
@@ -227,19 +269,27 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     }
     wave_sync();
   };
-  auto flush = [&](int s_lo, int s_hi, int64_t n_slot0) __attribute__((always_inline)) {
+  // the state leaves of one window class (short: W steps, NPC pieces per run; long: W2, NPC2), slots [s_lo, s_hi]
+  auto flush_leaves = [&](auto np_tag, auto long_tag, int s_lo, int s_hi, int64_t n_slot0) __attribute__((always_inline)) {
+    constexpr int NPG = decltype(np_tag)::value;
+    constexpr bool LONGC = decltype(long_tag)::value;
+    const bool fast = full_wave && (s_lo == 0) && (s_hi == NPG * VW - 1);
+    const int64_t row_u = env0 * rowlen + n_slot0;
+    const int pi = lane % NPG;
+    const unsigned lane_rows = (unsigned)((int64_t)P * (lane - pi) * rowlen);  // rows between lane 0's and the group's first environment
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      if (is_long(j) != LONGC) continue;
+      put_pieces(np_tag, [&](int h) __attribute__((always_inline)) { return ring_get(j, h); });
+      emit_lines(np_tag, ka.straj[j] + row_u, (int64_t)P * rowlen, lane_rows + (unsigned)(pi * VW), fast, s_lo, s_hi,
+                 [&](int h) { return pi * VW + h; });
+    }
+  };
+  // lb: slot of the long windows that holds the row in slot 0 of the short window being flushed (0 or W; wave-uniform)
+  auto flush = [&](int s_lo, int s_hi, int64_t n_slot0, int lb) __attribute__((always_inline)) {
     const bool fast = full_wave && (s_lo == 0) && (s_hi == W - 1);
     const int64_t row_u = env0 * rowlen + n_slot0;                               // (lane 0's environment, slot 0), in rows: uniform
-    if (with_states) {
-      const int pi = lane % NPC;
-      const unsigned lane_rows = (unsigned)((int64_t)P * (lane - pi) * rowlen);  // rows between lane 0's and the group's first environment
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        put_pieces([&](int h) __attribute__((always_inline)) { return ring_get(j, h); });
-        emit_lines(std::integral_constant<int, NPC>{}, ka.straj[j] + row_u, (int64_t)P * rowlen, lane_rows + (unsigned)(pi * VW), fast, s_lo,
-                   s_hi, [&](int h) { return pi * VW + h; });
-      }
-    }
+    if (with_states) flush_leaves(std::integral_constant<int, NPC>{}, std::false_type{}, s_lo, s_hi, n_slot0);
     // observation lines: line l of the window holds rows [l * RPO, (l + 1) * RPO)
     const int po = lane % NPL;
     const unsigned lane_rows_o = (unsigned)((int64_t)P * (lane - po) * rowlen);
@@ -251,7 +301,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
       auto row = [&](int t) __attribute__((always_inline)) {
         T fs[S], ob[O];
 #pragma unroll
-        for (int j = 0; j < S; ++j) fs[j] = ring_get(j, l * RPO + t);
+        for (int j = 0; j < S; ++j) fs[j] = ring_get(j, l * RPO + t + (is_long(j) ? lb : 0));
         M::observe(fs, c, ob);
         if constexpr (O >= VW) {
 #pragma unroll
@@ -268,10 +318,16 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
           for (int q = 0; q < O; ++q) xp[(i * EM_LANES + (lane ^ i)) * VW + (t * O + q) % VW] = ob[q];
         }
       };
-      if constexpr (NR <= 2) {  // small models: the rows of a line as straight-line code
+      if constexpr (NR <= 2 || EXCENV_EMR_ROW_UNROLL >= RPO) {  // the rows of a line as straight-line code
 #pragma unroll
         for (int t = 0; t < RPO; ++t) row(t);
-      } else {  // one row at a time: the rows' chains interleaved by the scheduler cost registers the ring needs
+      } else if constexpr (EXCENV_EMR_ROW_UNROLL == 2 && RPO % 2 == 0) {  // two rows' chains interleaved by the scheduler
+#pragma unroll 1
+        for (int t = 0; t < RPO; t += 2) {
+          row(t);
+          row(t + 1);
+        }
+      } else {  // one row at a time: interleaved chains cost registers the ring needs
 #pragma unroll 1
         for (int t = 0; t < RPO; ++t) row(t);
       }
@@ -282,44 +338,20 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     }
   };
 
-  // The next action line: prefetched a whole line ahead into 32 registers that stay live through the loop (PMSM fp32: +5 ... 8 %
-  // over loading at the crossing, and its 64-byte windows leave the room), or loaded at the crossing, the SIMD's other waves
-  // covering the latency (the smaller models: those 32 registers are a third wave per SIMD; cart-pole 0.45 -> 0.50, pendulum
-  // 0.51 -> 0.54; PMSM fp64: they are what keeps the kernel from spilling).
-  constexpr bool PREFETCH = M::IS_PMSM && sizeof(T) == 4;
-  T lineR[PREFETCH ? WL : 1];
-  {
-    T first[WL];
-    load_line(0, first);
-    park_line(first);
-  }
-  int lidx = 0;  // number of the line in the slot
-  const int last_line = (pha + (N - 1) * A) / WL;  // the line that holds the lane's last action row (wave-uniform)
-  if constexpr (PREFETCH) load_line(last_line < 1 ? last_line : 1, lineR);
+  dma_window(0);
   T a_cur[A], sv[S];
-  wave_sync();
-  read_row(pha, a_cur);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once per trajectory: the first window (and the initial state) is there
+  read_row(0, a_cur);
 
   for (int n = 0; n <= N; ++n) {
-    const int slot = (ph + n) % W;
-    // Row n + 1 of the actions (clamped) is what this step still needs (row n is in a_cur). When it starts the next line, that
-    // line is fetched into the slot (wave-uniform).
+    const int slot = (ph + n) % W, slot2 = (ph2 + n) % W2;
+    // Row n + 1 of the actions (clamped) is what this step still needs (row n is in a_cur). Its window was requested during the
+    // previous step, behind that step's flush and in front of its integration: nothing younger is in flight, so waiting for
+    // everything outstanding waits for exactly that fill (and for older stores, which retire before it anyway).
     const int k1 = (n + 1 < N) ? n + 1 : N - 1;
-    const int pos1 = pha + k1 * A;
-    if (!(EXCENV_EMR_DEBUG & 1) && n < N && pos1 / WL != lidx) {
-      ++lidx;
-      if constexpr (PREFETCH) {
-        park_line(lineR);
-        load_line(lidx + 1 < last_line ? lidx + 1 : last_line, lineR);  // never past the lane's own rows (a neighbour's line)
-      } else {
-        T nl[WL];
-        load_line(lidx, nl);
-        park_line(nl);
-      }
-      wave_sync();
-    }
+    if (!(EXCENV_EMR_DEBUG & 1) && k1 % ARW == 0 && k1 / ARW == w_hi && w_hi > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     T a_nxt[A];  // requested here, used by the integration below: the save in between covers the LDS latency
-    read_row(pos1 % WL, a_nxt);
+    read_row(k1, a_nxt);
 #pragma unroll
     for (int j = 0; j < S; ++j) sv[j] = st[j];
     if constexpr (AHEAD) {
@@ -335,11 +367,32 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
       }
     }
 #pragma unroll
-    for (int j = 0; j < S; ++j)
-      if (j != CL && j != DL) ring[ridx(j)][slot] = sv[j];
+    for (int j = 0; j < S; ++j) {
+      if (j == CL || j == DL) continue;
+      if constexpr (NRL > 0) {
+        if (is_long(j)) {
+          ringL[ridx(j)][slot2] = sv[j];
+          continue;
+        }
+      }
+      ring[ridx(j)][slot] = sv[j];
+    }
     if (!(EXCENV_EMR_DEBUG & 2) && (slot == W - 1 || n == N)) {
       const int back = (n < slot) ? n : slot;  // rows of the window before row n
-      flush(slot - back, slot, n - slot);
+      flush(slot - back, slot, n - slot, slot2 - slot);
+      if constexpr (W2 != W) {  // the long leaves' window ends at every second short one (and with the trajectory)
+        if (with_states && (slot2 == W2 - 1 || n == N)) {
+          const int back2 = (n < slot2) ? n : slot2;
+          flush_leaves(std::integral_constant<int, NPC2>{}, std::true_type{}, slot2 - back2, slot2, n - slot2);
+        }
+      }
+    }
+    // row k1 was the last of its action window: the window's LDS is dead (its reads have returned by now; made formal) and
+    // takes the next one — behind the flush, so that the wait at the top of the next step does not drain this step's stores
+    if (!(EXCENV_EMR_DEBUG & 1) && n < N && k1 % ARW == ARW - 1 && k1 / ARW == w_hi && (w_hi + 1) * ANP < n_pieces) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ++w_hi;
+      dma_window(w_hi);
     }
     if (n < N) {
       if constexpr (AHEAD) {

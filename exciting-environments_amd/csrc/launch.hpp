@@ -386,7 +386,15 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
     EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, GEN, VV, ST, false>), grid, block, (size_t)sc.lds_pad, sc.stream, ka); \
     return;                                                                                                                     \
   } while (0)
-  if (general) EXCENV_SIM_LAUNCH(true, 1, -1);
+  if (general) {
+    if (ka.truncated == nullptr) {  // no gym trajectories: the instantiations without their code
+      if constexpr (!M::HAS_LUT && sizeof(T) == 4) {  // fp64: two property sets do not fit next to a second wave (PMSM: 380 registers)
+        if (V == 2) EXCENV_SIM_LAUNCH(true, 2, -2);  // two environments per lane, each with its own property set
+      }
+      EXCENV_SIM_LAUNCH(true, 1, -2);
+    }
+    EXCENV_SIM_LAUNCH(true, 1, -1);
+  }
   if (ka.straj[0] == nullptr) {  // observations only: its own instantiations (no state stores between the action loads and their waits)
     if constexpr (sizeof(T) == 4) {
       if (V == 4) EXCENV_SIM_LAUNCH(false, 4, 0);
@@ -428,7 +436,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     for (int j = 0; j < ka.n_control; ++j) split_control &= sc.control->reference[j] != nullptr;
   }
   bool general = batched || (ka.n_control > 0 && !split_control) || with_gym;
-  bool vec_ok = !general;
+  bool vec_ok = true;  // every pointer 16-byte aligned (checked below); the general instantiation goes up to two environments per lane
   for (int j = 0; j < M::S; ++j) {
     if (!sc.state_in[j] || !sc.last_state[j]) { set_error("excenv_sim_ahead: state pointer %d is NULL", j); return EXCENV_ENULL; }
     ka.state_in[j] = (const T*)sc.state_in[j];
@@ -504,11 +512,13 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     // register-ring form (kernels_emr.hpp): whole-line stores. Needs 128-byte aligned trajectory arrays and enough environments
     // to fill waves whose lanes are P environments apart.
     const bool ahead = sc.semantics == EXCENV_SEM_AHEAD;
-    const int64_t W = ahead ? emr_rows<M, T, true>() : emr_rows<M, T, false>(), WL = 128 / (int64_t)sizeof(T);
+    const int64_t W = ahead ? emr_rows_long<M, T, true>() : emr_rows_long<M, T, false>(), WL = 128 / (int64_t)sizeof(T);  // the longest window
     auto period = [](int64_t x, int64_t m) { int64_t g = m, y = x % m; while (y) { const int64_t t = g % y; g = y; y = t; } return m / g; };
-    const int64_t Ps = period(sc.K + 1, W), Pa = period(sc.K * M::A, WL);
-    const int64_t P = Ps > Pa ? Ps : Pa;
+    const int64_t P = period(sc.K + 1, W);
+    (void)WL;
+    // action rows must consist of whole 16-byte pieces (they are fetched as 64-byte windows by LDS-direct loads)
     bool ok = ((uintptr_t)ka.obs % 128) == 0 && (sc.em_mode == 4 || sc.B >= 16 * EM_LANES * P) &&
+              (sc.K * M::A * (int64_t)sizeof(T)) % 16 == 0 && aligned16(ka.actions) &&
               EM_LANES * P * (sc.K + 1) * M::O * (int64_t)sizeof(T) < ((int64_t)1 << 31);  // 32-bit lane offsets
     for (int j = 0; j < M::S; ++j) ok &= ka.straj[j] == nullptr || ((uintptr_t)ka.straj[j] % 128) == 0;
     if (ok) {
@@ -565,6 +575,14 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   vec_ok &= aligned16(ka.actions) && aligned16(ka.obs);
   constexpr int VMAX = 16 / (int)sizeof(T);
   int V = 1;
+  if (general) {
+    // per-environment property sets / control columns / gym trajectories: two environments per lane (each with its own Ctx) where
+    // the batch fills the chip that way and everything is lane-major; else one
+    bool two = vec_ok && !M::HAS_LUT && sizeof(T) == 4 && sc.action_layout == EXCENV_LAYOUT_LANE_MAJOR && sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR &&
+               (sc.B % 2) == 0 && (sc.vec_pref > 0 ? sc.vec_pref >= 2 : auto_envs_per_lane(sc.B, 2) == 2);
+    V = (two && !with_gym) ? 2 : 1;
+    vec_ok = false;
+  }
   if (vec_ok) {
     int want = sc.vec_pref > 0 ? sc.vec_pref : auto_envs_per_lane(sc.B, VMAX);
     // acrobot RK4 / Tsit5 is VALU-bound with the largest register footprint of all instantiations: two envs per lane keep
@@ -617,7 +635,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
   }
 #undef EXCENV_SIM_CASE
-  g_last_launch = general ? "sim_ahead_kernel (general)" : (aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? "sim_ahead_kernel (V=2)" : "sim_ahead_kernel (V=4)")));
+  g_last_launch = general ? (V == 2 ? "sim_ahead_kernel (general, V=2)" : "sim_ahead_kernel (general)") : (aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? "sim_ahead_kernel (V=2)" : "sim_ahead_kernel (V=4)")));
   if (int rc = check_launch("excenv_sim_ahead")) return rc;
   if (split_control && !general) {
     ControlFillArgs<T, M> fa;

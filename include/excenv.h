@@ -162,7 +162,7 @@ typedef struct {
 int excenv_abi_version(void);
 const char* excenv_last_error(void);
 /* Name of the trajectory-kernel form the last excenv_sim_ahead[_ws] call of this thread enqueued ("" before the first):
- * "sim_ahead_kernel (V=1|V=2|V=4)", "sim_ahead_kernel (general)", "sim_ahead_kernel (row-major actions fused)",
+ * "sim_ahead_kernel (V=1|V=2|V=4)", "sim_ahead_kernel (general[, V=2])", "sim_ahead_kernel (row-major actions fused)",
  * "sim_ahead_emr_kernel", "sim_ahead_em_kernel[ (general)]", "transposition workspace + sim_ahead_kernel". Informational
  * (tests assert that the path they mean to check is the one that ran). */
 const char* excenv_last_launch(void);
