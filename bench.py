@@ -596,6 +596,12 @@ def main():
         out["per_rank_kernel_ms"] = [[round(x, 4) for x in r[:3]] for r in per_rank]
         out["per_rank_steps_wall_ms"] = [round(r[3], 3) for r in per_rank]
         out["gather_ms"] = (None if all(r[4] < 0 for r in per_rank) else max(r[4] for r in per_rank))
+        # `value` keeps the contract (everything inside the timed region, the end all-gather included). The collective is ONE
+        # per run whatever --steps is (1.07 GB received per rank at 8 x 2^22 environments: 3 - 10 ms over xGMI against
+        # steps x 5 ms of stepping), so its share shrinks with the number of steps: the rate without it is reported beside it.
+        if out["gather_ms"] is not None and args.steps:
+            out["value_without_end_gather"] = total_steps / max(elapsed - out["gather_ms"] * 1e-3, 1e-9)
+            out["end_gather_share_of_timed_region"] = out["gather_ms"] * 1e-3 / elapsed
         med_rank = float(np.median([r[1] for r in per_rank]))
         slow_rank = float(np.max([r[1] for r in per_rank]))
         # whole-job rate if every rank ran its launches at the median rank's / the slowest rank's median kernel time (no gather):

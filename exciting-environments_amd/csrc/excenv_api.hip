@@ -3,6 +3,7 @@
 // no synchronisation — only kernel enqueues on the caller's stream.
 #include <cstdarg>
 #include <cstdio>
+#include <dlfcn.h>
 #include "launch.hpp"
 
 namespace excenv {
@@ -382,6 +383,48 @@ int excenv_random_state(int env, int dtype, int64_t B, const excenv_props_t* pro
   if (!t) return trc;
   RandomStateCall rc{dtype, B, props, keys, state_out, key_leaf, (hipStream_t)stream};
   return t->random_state(rc);
+}
+
+// ---- the one collective of the path: reassemble observations on every rank -------------------------------
+// RCCL is resolved at run time (dlopen: librccl.so, the library torch.distributed's "nccl" backend uses on ROCm) so that
+// single-GPU users of libexcenv_hip.so do not need it; the communicator is the caller's.
+namespace {
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+nccl_allgather_fn resolve_allgather(const char** why) {
+  static nccl_allgather_fn fn = nullptr;
+  static const char* err = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) {
+      h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) err = "librccl.so could not be loaded";
+    else {
+      fn = (nccl_allgather_fn)dlsym(h, "ncclAllGather");
+      if (!fn) err = "librccl.so has no ncclAllGather";
+    }
+  }
+  if (why) *why = err;
+  return fn;
+}
+}  // namespace
+
+int excenv_allgather(void* nccl_comm, int dtype, const void* send, void* recv, int64_t count_per_rank, void* stream) {
+  if (dtype != EXCENV_F32 && dtype != EXCENV_F64) { set_error("excenv_allgather: bad dtype id %d", dtype); return EXCENV_EINVAL; }
+  if (count_per_rank < 0) { set_error("excenv_allgather: bad count %lld", (long long)count_per_rank); return EXCENV_EINVAL; }
+  if (!nccl_comm || ((!send || !recv) && count_per_rank > 0)) { set_error("excenv_allgather: NULL argument"); return EXCENV_ENULL; }
+  if (count_per_rank == 0) return EXCENV_OK;
+  const char* why = nullptr;
+  nccl_allgather_fn fn = resolve_allgather(&why);
+  if (!fn) { set_error("excenv_allgather: %s", why ? why : "RCCL unavailable"); return EXCENV_EUNSUPPORTED; }
+  const int nccl_type = dtype == EXCENV_F32 ? 7 : 8;  // ncclFloat32 / ncclFloat64 (rccl.h)
+  const int rc = fn(send, recv, (size_t)count_per_rank, nccl_type, nccl_comm, (hipStream_t)stream);
+  if (rc != 0) { set_error("excenv_allgather: ncclAllGather failed with ncclResult_t %d", rc); return EXCENV_EHIP; }
+  return EXCENV_OK;
 }
 
 int excenv_probe_math(int which, int dtype, int64_t n, const void* in, void* out, void* stream) {

@@ -224,6 +224,17 @@ template <typename T, int N> __device__ __forceinline__ void load_row(const T* s
   }
 }
 
+// V one-byte flags of V adjacent environments as ONE store (lane-major flag trajectories; p is V-byte aligned)
+template <int V> __device__ __forceinline__ void store_flags(uint8_t* p, const uint8_t (&f)[V]) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<uint32_t*>(p) = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
+  } else if constexpr (V == 2) {
+    *reinterpret_cast<uint16_t*>(p) = (uint16_t)((uint16_t)f[0] | ((uint16_t)f[1] << 8));
+  } else {
+    *p = f[0];
+  }
+}
+
 // ---- gym outputs of one saved state (generate_reward / generate_terminated / generate_truncated) ----------------
 // `ob` is the observation row of `st` (without control columns); `ref[j]` the physical reference of control column j.
 // Stores through the three element pointers (reward, terminated: one element; truncated: TW flags, stride t_sc).
@@ -405,16 +416,21 @@ constexpr int AEM_BLOCK_BYTES = 1024 + 16;  // one LDS-direct load instruction's
 template <class M> constexpr int aem_np() { return M::ID == EXCENV_ACROBOT ? 2 : EXCENV_AEM_NP; }
 template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return (size_t)(BLOCK / 64) * V * aem_np<M>() * AEM_BLOCK_BYTES; }
 
-template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false>
+// LGYM (round 4; PMSM, lean, V * sizeof(T) == 16): the reward / terminated / truncated trajectories of core_env.py:490-531 written by
+// the wide kernel itself — PMSM's reward (pmsm_env.py:985-1037) needs three references per environment and ~40 instructions, its
+// flags are one byte each (|i_dq| > 1), so the four environments of a lane add a 16-byte reward store and two packed 4-byte flag
+// stores per row. The general instantiation (one environment per lane, byte stores) took 6.8 ms for the launch the lean kernel
+// does in 4.8; the other models' rewards (two sin / cos pairs per controlled angle, up to eight controls) stay there.
+template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false, bool LGYM = false>
 __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
-  // GENERAL with V = 2 (round 4): every environment of a lane carries its own property set (a second Ctx in registers), so that
-  // per-environment property arrays and control columns keep 8-byte accesses and 512-byte rows per wave at large batches (one
-  // environment per lane: 0.57 of the roof whatever the instantiation, two: 0.7). Only without the gym outputs (STATES == -2:
-  // their code is compiled out; with it the save-row code of two environments is not inlined any more and the property sets
-  // end up in scratch memory) and not for the look-up models (registers).
-  static_assert(!(GENERAL && (V > 2 || (V == 2 && (M::HAS_LUT || STATES != -2)))), "per-environment property sets: at most two environments per lane");
+  // GENERAL stays at one environment per lane. Round 4 tried two, each with its own property set (a second Ctx in registers:
+  // every leaf may differ per environment, so none can stay in SGPRs — 195 registers, two waves per SIMD): 5.91 ... 6.27 ms for one,
+  // 6.02 ... 6.06 for two (tools/general_path_cost.py, two sessions) — no gain, removed. What did help is compiling the gym
+  // outputs' code out where none are asked for (STATES == -2): 0.569 -> 0.60 of the roof, the lean one-environment form's level.
+  static_assert(!(GENERAL && V > 1), "per-environment property sets: one environment per lane");
   static_assert(GENERAL == (STATES < 0), "STATES -1 / -2 (general, with / without the gym outputs' code) and 0 / 1 (lean)");
+  static_assert(!LGYM || (!GENERAL && M::IS_PMSM && !M::HAS_LUT && aem_shape_ok<T, V>()), "lean gym outputs: PMSM, widest lean form");
   constexpr int NC = GENERAL ? V : 1;  // property sets per lane
   constexpr bool GYM = GENERAL && STATES == -1;
   static_assert(!AEM || (!GENERAL && !M::HAS_LUT && aem_shape_ok<T, V>() && (16 / (int)sizeof(T)) % A == 0),
@@ -452,6 +468,30 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
       aux[v].eps0 = st[v][2];
       aux[v].prev_clip[0] = st[v][0];
       aux[v].prev_clip[1] = st[v][1];
+    }
+  }
+  // LGYM: the references of the controlled fields among i_d (3), i_q (4), torque (5), per environment of the lane
+  T g_id[V], g_iq[V], g_tq[V];
+  bool has_id = false, has_iq = false, has_tq = false;
+  if constexpr (LGYM) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) g_id[v] = g_iq[v] = g_tq[v] = T(0);
+#pragma unroll
+    for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+      if (j < ka.n_control) {
+        const int f = ka.control_idx[j];
+        T tmp[V];
+        load_v<T, V>(ka.reference[j] + blk0 + lane_env, tmp);
+        if (f == 3) has_id = true;
+        if (f == 4) has_iq = true;
+        if (f == 5) has_tq = true;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          g_id[v] = (f == 3) ? tmp[v] : g_id[v];
+          g_iq[v] = (f == 4) ? tmp[v] : g_iq[v];
+          g_tq[v] = (f == 5) ? tmp[v] : g_tq[v];
+        }
+      }
     }
   }
   const bool deadtime_on = (M::IS_PMSM) ? (c.P[M::P - 1] > T(0)) : false;
@@ -546,6 +586,22 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
 #pragma unroll
         for (int v = 0; v < V; ++v) tmp[v] = sv[v][j];
         store_stream<T, V>(ka.straj[j] + s_blk + n * ka.s_sk + s_lane, tmp);
+      }
+    }
+    if constexpr (LGYM) {  // the same outputs for the V environments of a lane: truncated row n, reward / terminated row n - 1
+      T rew[V];
+      uint8_t fl[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        rew[v] = pmsm_reward<M, T>(sv[v], c, has_id, g_id[v], has_iq, g_iq[v], has_tq, g_tq[v]);
+        const T nd = normalize(sv[v][3], c.smin[3], c.smax[3]), nq = normalize(sv[v][4], c.smin[4], c.smax[4]);
+        fl[v] = xsqrt(nd * nd + nq * nq) > T(1);  // pmsm_env.py:972-983: terminated == truncated
+      }
+      const int64_t e0 = blk0 + lane_env;
+      store_flags<V>(ka.truncated + n * ka.t_sk + e0, fl);
+      if (n > 0) {
+        store_stream<T, V>(ka.reward + (n - 1) * ka.g_sk + e0, rew);
+        store_flags<V>(ka.terminated + (n - 1) * ka.g_sk + e0, fl);
       }
     }
     if constexpr (GYM) {  // core_env.py:490-531: truncated on every row, reward / terminated on rows 1..N (V == 1 here)

@@ -359,12 +359,20 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
 }
 
 template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(const SimCall& sc_in, const SimArgs<T, M>& ka_in,
-                                                                                 bool general, int V, bool aem = false) {
+                                                                                 bool general, int V, bool aem = false, bool lgym = false) {
   SimArgs<T, M> ka = ka_in;
   SimCall sc = sc_in;
   sc.lds_pad = (int)lut_lds_bytes<T, M>(ka.kp, (size_t)sc_in.lds_pad);
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
+  if constexpr (M::IS_PMSM && !M::HAS_LUT) {
+    if (lgym) {  // PMSM's gym trajectories out of the widest lean form (V == 16 / sizeof(T), lean_gym_applies)
+      constexpr int VA = 16 / (int)sizeof(T);
+      if (ka.straj[0] == nullptr) EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 0, false, false, true>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
+      else EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 1, false, false, true>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
+      return;
+    }
+  }
   if constexpr (!M::HAS_LUT && (16 / (int)sizeof(T)) % M::A == 0) {
     if (aem) {  // row-major actions through the per-wave LDS piece ring: V == 16 / sizeof(T) (aem_applies)
       constexpr int VA = 16 / (int)sizeof(T);
@@ -387,12 +395,7 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
     return;                                                                                                                     \
   } while (0)
   if (general) {
-    if (ka.truncated == nullptr) {  // no gym trajectories: the instantiations without their code
-      if constexpr (!M::HAS_LUT && sizeof(T) == 4) {  // fp64: two property sets do not fit next to a second wave (PMSM: 380 registers)
-        if (V == 2) EXCENV_SIM_LAUNCH(true, 2, -2);  // two environments per lane, each with its own property set
-      }
-      EXCENV_SIM_LAUNCH(true, 1, -2);
-    }
+    if (ka.truncated == nullptr) EXCENV_SIM_LAUNCH(true, 1, -2);  // no gym trajectories: the instantiation without their code
     EXCENV_SIM_LAUNCH(true, 1, -1);
   }
   if (ka.straj[0] == nullptr) {  // observations only: its own instantiations (no state stores between the action loads and their waits)
@@ -430,12 +433,20 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   // control_state columns alone (broadcast properties, no gym outputs, lane-major / tiled trajectories) do not need the
   // one-environment-per-lane GENERAL kernel: they are constant along the trajectory and are filled by control_fill_kernel
   // after the lean kernel has written everything else (same bytes, +1 launch, 0.52 -> 0.7 of the HBM roof at B = 2^22)
-  bool split_control = !batched && !with_gym && ka.n_control > 0 && sc.traj_layout != EXCENV_LAYOUT_ENV_MAJOR &&
+  // PMSM's gym trajectories come out of the widest lean form too (kernels.hpp, LGYM) when everything is lane-major, the batch
+  // runs that form anyway and the flag / reward / reference arrays allow vector accesses
+  constexpr int VMAXG = 16 / (int)sizeof(T);
+  bool lean_gym = with_gym && !batched && M::IS_PMSM && !M::HAS_LUT && sc.action_layout == EXCENV_LAYOUT_LANE_MAJOR &&
+                  sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR && sc.B > 0 && (sc.B % VMAXG) == 0 &&
+                  (sc.vec_pref > 0 ? sc.vec_pref == VMAXG : auto_envs_per_lane(sc.B, VMAXG) == VMAXG) &&
+                  aligned16(sc.gym->reward) && ((uintptr_t)sc.gym->terminated % VMAXG) == 0 && ((uintptr_t)sc.gym->truncated % VMAXG) == 0;
+  for (int j = 0; lean_gym && j < ka.n_control; ++j) lean_gym = sc.control->reference[j] != nullptr && aligned16(sc.control->reference[j]);
+  bool split_control = !batched && (!with_gym || lean_gym) && ka.n_control > 0 && sc.traj_layout != EXCENV_LAYOUT_ENV_MAJOR &&
                        sc.action_layout != EXCENV_LAYOUT_ENV_MAJOR && sc.B > 0;
   if (split_control) {
     for (int j = 0; j < ka.n_control; ++j) split_control &= sc.control->reference[j] != nullptr;
   }
-  bool general = batched || (ka.n_control > 0 && !split_control) || with_gym;
+  bool general = batched || (ka.n_control > 0 && !split_control) || (with_gym && !lean_gym);
   bool vec_ok = true;  // every pointer 16-byte aligned (checked below); the general instantiation goes up to two environments per lane
   for (int j = 0; j < M::S; ++j) {
     if (!sc.state_in[j] || !sc.last_state[j]) { set_error("excenv_sim_ahead: state pointer %d is NULL", j); return EXCENV_ENULL; }
@@ -575,14 +586,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   vec_ok &= aligned16(ka.actions) && aligned16(ka.obs);
   constexpr int VMAX = 16 / (int)sizeof(T);
   int V = 1;
-  if (general) {
-    // per-environment property sets / control columns / gym trajectories: two environments per lane (each with its own Ctx) where
-    // the batch fills the chip that way and everything is lane-major; else one
-    bool two = vec_ok && !M::HAS_LUT && sizeof(T) == 4 && sc.action_layout == EXCENV_LAYOUT_LANE_MAJOR && sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR &&
-               (sc.B % 2) == 0 && (sc.vec_pref > 0 ? sc.vec_pref >= 2 : auto_envs_per_lane(sc.B, 2) == 2);
-    V = (two && !with_gym) ? 2 : 1;
-    vec_ok = false;
-  }
+  if (general) vec_ok = false;  // one environment per lane (two, each with its own property set, measured no faster: DESIGN.md §4.1)
   if (vec_ok) {
     int want = sc.vec_pref > 0 ? sc.vec_pref : auto_envs_per_lane(sc.B, VMAX);
     // acrobot RK4 / Tsit5 is VALU-bound with the largest register footprint of all instantiations: two envs per lane keep
@@ -599,6 +603,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     while (want > 1 && (sc.B % want) != 0) want >>= 1;
     V = want;
   }
+  if (lean_gym && (general || V != VMAX)) { set_error("excenv_sim_ahead: internal error: lean gym outputs need %d environments per lane", VMAX); return EXCENV_EINVAL; }
   if (aem && V != VMAX) { set_error("excenv_sim_ahead: internal error: fused row-major actions need %d environments per lane", VMAX); return EXCENV_EINVAL; }
   if (tiled_a || tiled_t) {  // a workgroup must not straddle tiles
     constexpr int VT = (int)(TILE / BLOCK);
@@ -625,8 +630,8 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   }
 #define EXCENV_SIM_CASE(SOLV)                                                         \
   case SOLV:                                                                          \
-    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(sc, ka, general, V, aem && V == VMAX);  \
-    else launch_sim_v<M, T, SOLV, false>(sc, ka, general, V, aem && V == VMAX);                         \
+    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(sc, ka, general, V, aem && V == VMAX, lean_gym);  \
+    else launch_sim_v<M, T, SOLV, false>(sc, ka, general, V, aem && V == VMAX, lean_gym);                         \
     break;
   switch (sc.solver) {
     EXCENV_SIM_CASE(EXCENV_EULER)
@@ -635,7 +640,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
   }
 #undef EXCENV_SIM_CASE
-  g_last_launch = general ? (V == 2 ? "sim_ahead_kernel (general, V=2)" : "sim_ahead_kernel (general)") : (aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? "sim_ahead_kernel (V=2)" : "sim_ahead_kernel (V=4)")));
+  g_last_launch = general ? "sim_ahead_kernel (general)" : (lean_gym ? "sim_ahead_kernel (lean, gym outputs)" : aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? "sim_ahead_kernel (V=2)" : "sim_ahead_kernel (V=4)")));
   if (int rc = check_launch("excenv_sim_ahead")) return rc;
   if (split_control && !general) {
     ControlFillArgs<T, M> fa;

@@ -472,6 +472,38 @@ __device__ __forceinline__ void pick_field(const T (&st)[M::S], const Ctx<T, M>&
 
 // e.g. pendulum_env.py:297-309, mass_spring_damper_env.py:296-302, pmsm_env.py:985-1037. The control loop is unrolled
 // over EXCENV_MAX_CONTROL with a uniform guard so that `ref` (registers) is only indexed statically.
+// PMSM reward (pmsm_env.py:985-1037) from the references of the controlled fields among i_d, i_q, torque: one function for the
+// general instantiation (which finds them by scanning control_idx) and the lean gym instantiation (which holds them per
+// environment of a lane) — same operations, same order, same bits.
+template <class M, typename T>
+__device__ __forceinline__ T pmsm_reward(const T (&st)[M::S], const Ctx<T, M>& c, bool has_id, T r_id, bool has_iq, T r_iq,
+                                         bool has_tq, T r_tq) {
+  T reward = T(0);
+  const T i_d = normalize(st[3], c.smin[3], c.smax[3]);
+  const T i_q = normalize(st[4], c.smin[4], c.smax[4]);
+  if (has_id && has_iq) {  // current_reward_func (pmsm_env.py:1010-1012), gamma = 0.85
+    const T dd = i_d - normalize(r_id, c.smin[3], c.smax[3]);
+    const T dq = i_q - normalize(r_iq, c.smin[4], c.smax[4]);
+    const T mse = T(0.5) * (dd * dd) + T(0.5) * (dq * dq);
+    reward = reward + T(-1) * (mse * T(1 - 0.85));
+  }
+  if (has_tq) {  // torque_reward_func(i_d, i_q, torque, torque_ref, 1, 0.85) (pmsm_env.py:1014-1037)
+    const T tq = normalize(st[5], c.smin[5], c.smax[5]);
+    const T tr = normalize(r_tq, c.smin[5], c.smax[5]);
+    const T i_s = xsqrt(i_d * i_d + i_q * i_q);
+    const T i_n = T(1), i_d_plus = T(0.2) * i_n, tol = T(0.01);
+    T rew = T(0);
+    rew = (i_s > T(1)) ? T(-1) * xabs(i_s) : rew;
+    rew = ((i_s < T(1)) && (i_s > i_n)) ? T(0.5) * (T(1) - (i_s - i_n) / (T(1) - i_n)) - T(1) : rew;
+    rew = ((i_s < i_n) && (i_d > i_d_plus)) ? T(-0.5) * ((i_d - i_d_plus) / (i_n - i_d_plus)) : rew;
+    const T ad = xabs(tq - tr);
+    rew = ((i_s < i_n) && (i_d < i_d_plus) && (ad > tol)) ? T(0.5) * (T(1) - xabs((tr - tq) / T(2))) : rew;
+    rew = ((i_s < i_n) && (i_d < i_d_plus) && (ad < tol)) ? T(1) - T(0.5) * i_s : rew;
+    reward = reward + rew * T(1 - 0.85);
+  }
+  return reward;
+}
+
 template <class M, typename T>
 __device__ __forceinline__ T env_reward(const T (&st)[M::S], const Ctx<T, M>& c, int n_control, const int* idx,
                                         const T (&ref)[EXCENV_MAX_CONTROL]) {
@@ -489,28 +521,7 @@ __device__ __forceinline__ T env_reward(const T (&st)[M::S], const Ctx<T, M>& c,
         if (f == 5) { has_tq = true; r_tq = ref[j]; }
       }
     }
-    const T i_d = normalize(st[3], c.smin[3], c.smax[3]);
-    const T i_q = normalize(st[4], c.smin[4], c.smax[4]);
-    if (has_id && has_iq) {  // current_reward_func (pmsm_env.py:1010-1012), gamma = 0.85
-      const T dd = i_d - normalize(r_id, c.smin[3], c.smax[3]);
-      const T dq = i_q - normalize(r_iq, c.smin[4], c.smax[4]);
-      const T mse = T(0.5) * (dd * dd) + T(0.5) * (dq * dq);
-      reward = reward + T(-1) * (mse * T(1 - 0.85));
-    }
-    if (has_tq) {  // torque_reward_func(i_d, i_q, torque, torque_ref, 1, 0.85) (pmsm_env.py:1014-1037)
-      const T tq = normalize(st[5], c.smin[5], c.smax[5]);
-      const T tr = normalize(r_tq, c.smin[5], c.smax[5]);
-      const T i_s = xsqrt(i_d * i_d + i_q * i_q);
-      const T i_n = T(1), i_d_plus = T(0.2) * i_n, tol = T(0.01);
-      T rew = T(0);
-      rew = (i_s > T(1)) ? T(-1) * xabs(i_s) : rew;
-      rew = ((i_s < T(1)) && (i_s > i_n)) ? T(0.5) * (T(1) - (i_s - i_n) / (T(1) - i_n)) - T(1) : rew;
-      rew = ((i_s < i_n) && (i_d > i_d_plus)) ? T(-0.5) * ((i_d - i_d_plus) / (i_n - i_d_plus)) : rew;
-      const T ad = xabs(tq - tr);
-      rew = ((i_s < i_n) && (i_d < i_d_plus) && (ad > tol)) ? T(0.5) * (T(1) - xabs((tr - tq) / T(2))) : rew;
-      rew = ((i_s < i_n) && (i_d < i_d_plus) && (ad < tol)) ? T(1) - T(0.5) * i_s : rew;
-      reward = reward + rew * T(1 - 0.85);
-    }
+    reward = pmsm_reward<M, T>(st, c, has_id, r_id, has_iq, r_iq, has_tq, r_tq);
   } else {
 #pragma unroll
     for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {

@@ -92,7 +92,8 @@ def lib():
         l.excenv_truncated_width.restype = ctypes.c_int32
         for fn in ("excenv_step", "excenv_gym_step", "excenv_sim_ahead", "excenv_sim_ahead_ws", "excenv_transpose", "excenv_env_dims",
                    "excenv_probe_math", "excenv_probe_div", "excenv_rew_trunc_term", "excenv_state_from_observation",
-                   "excenv_update_ref", "excenv_update_ref_to", "excenv_random_state", "excenv_observe", "excenv_stream_pattern"):
+                   "excenv_update_ref", "excenv_update_ref_to", "excenv_random_state", "excenv_observe", "excenv_stream_pattern",
+                   "excenv_allgather"):
             getattr(l, fn).restype = ctypes.c_int
         vp, ci, cl, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
         # typed prototypes: plain Python ints / floats / None / byref() pass without per-call ctypes wrapping
@@ -113,6 +114,19 @@ def _check(rc: int, what: str):
     if rc != 0:
         msg = lib().excenv_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def allgather(nccl_comm: int, send: torch.Tensor, recv: torch.Tensor):
+    """excenv_allgather: ncclAllGather of `send` (this rank's contiguous slice) into `recv` ([world * send.numel()]) on torch's
+    current stream, through the caller's ncclComm_t handle (an integer address). The Python mirror's ObservationGatherer uses
+    torch.distributed instead; this is the entry point a non-torch binder would call."""
+    _require_device(send, "excenv_allgather")
+    assert send.is_contiguous() and recv.is_contiguous() and send.dtype == recv.dtype
+    with _on_device(send.device):
+        rc = lib().excenv_allgather(ctypes.c_void_p(nccl_comm), ctypes.c_int(dtype_id(send.dtype)), ctypes.c_void_p(send.data_ptr()),
+                                    ctypes.c_void_p(recv.data_ptr()), ctypes.c_int64(send.numel()),
+                                    ctypes.c_void_p(_raw_stream(send.device)))
+    _check(rc, "excenv_allgather")
 
 
 def last_launch() -> str:

@@ -127,12 +127,13 @@ class CoreEnvironment(ABC):
         # set is checked for a slow physical placement before its first use. Both are invisible to callers (the functional
         # contract holds: a set is handed out again only when nothing can observe it); knobs for experiments:
         self.trajectory_pool = True          # False: every large call allocates its outputs (the behaviour up to round 2)
-        self.trajectory_placement = "auto"   # "off": take the first placement the allocator gives
+        self.trajectory_placement = "auto"   # "auto": arena pair, search as fall-back; "search": round 3's search only; "off": none
         self.last_placement = None           # diagnostics of the most recent placement check (dict) or None
         self._traj_sets = []
         self._placement_best = {}
         self._placement_replaced = {}
         self._placement_target = None
+        self._arena_made = set()
         self._pool_wait_events = []
         self._traj_bcast_cache = None
         self._ws_bytes_cache = None
@@ -983,7 +984,7 @@ class CoreEnvironment(ABC):
     # outside torch's cache) stay allocated, so that it lands a region further on. The first set of a shape tries at least two
     # placements and stops when one is clearly (7 %) faster than another (both levels have shown themselves); later sets stop at
     # the first block that matches the best time known; at most _PLACEMENT_TRIES candidates, the fastest is kept, everything else
-    # is freed. Cost: ~4 launches per candidate, once per set. Sets are then pooled: a dead set (same test as the vmap_step
+    # is freed. Cost: 3 launches per candidate, once per set. Sets are then pooled: a dead set (same test as the vmap_step
     # slots: no Python reference, no C++ holder, no foreign view, same stream) is written again instead of allocating a new
     # one, so a chained run (`obs, states, last = env.vmap_sim_ahead(last, actions, ...)`) alternates between two placed sets.
     class _TrajSet:
@@ -994,6 +995,23 @@ class CoreEnvironment(ABC):
     _PLACEMENT_TRIES = 4
     _PLACEMENT_ACCEPT = 0.93      # fastest / slowest candidate at or below this: the two levels have both been seen
     _TRAJ_POOL_SETS = 2
+
+    @classmethod
+    def placement_memory_budget(cls, B: int, rows: int, OW: int, S: int, itemsize: int, free_bytes: int) -> dict:
+        """Upper bounds (bytes) of what pooling and placing the large output sets of one shape can hold on a device with
+        `free_bytes` free, for capacity planning (C5: 2^22 environments per GPU, 101 rows: 25.5 GB per set):
+          steady      : the pooled sets that stay allocated (_TRAJ_POOL_SETS sets: observations + state block + last states)
+          search_peak : the most a placement search holds at once on top of the OTHER pooled set — the new set's observations,
+                        up to _PLACEMENT_TRIES candidate state blocks and the spacers between them (each at most a third of what
+                        is free when it is taken, never more than _PLACEMENT_SPACER_BYTES)
+        A search that runs out of memory stops early and keeps the best candidate seen (torch.OutOfMemoryError is caught)."""
+        obs = rows * OW * B * itemsize
+        block = S * rows * B * itemsize
+        one = obs + block + S * B * itemsize
+        spacer = min(cls._PLACEMENT_SPACER_BYTES, max(free_bytes // 3, 0))
+        peak = obs + cls._PLACEMENT_TRIES * block + (cls._PLACEMENT_TRIES - 1) * spacer + spacer  # + the observation spacer of a replacement
+        return {"set": one, "steady": cls._TRAJ_POOL_SETS * one, "search_peak": one + peak,
+                "searches_at_most": 1 + cls._PLACEMENT_REPLACEMENTS + (cls._TRAJ_POOL_SETS - 1)}
 
     def release_trajectory_buffers(self):
         """Drop the pooled (dead) trajectory output sets so that their memory returns to torch's allocator."""
@@ -1010,7 +1028,7 @@ class CoreEnvironment(ABC):
         block_shape = (S, rows, B) if block_shape is None else block_shape  # env-major sets: (S, padded leaf elements)
         block = torch.empty(block_shape, dtype=dt, device=dev)
         nbytes = (OW + S) * rows * B * isz
-        if (self.trajectory_placement != "auto" or time_launch is None or nbytes < self._PLACED_TRAJ_BYTES
+        if (self.trajectory_placement not in ("auto", "search") or time_launch is None or nbytes < self._PLACED_TRAJ_BYTES
                 or torch.cuda.is_current_stream_capturing()):
             return block, None
         pkey = (B, rows, OW, S) + (() if len(block_shape) == 3 else ("env_major",))
@@ -1069,7 +1087,7 @@ class CoreEnvironment(ABC):
 
     def _traj_timed_launch(self, ts, launch_fn, nbytes):
         """Launch into a pooled, placed set with a pair of HIP events around it (two event records per multi-millisecond launch)."""
-        timed = (ts.rc0 is not None and self.trajectory_placement == "auto" and nbytes >= self._PLACED_TRAJ_BYTES
+        timed = (ts.rc0 is not None and self.trajectory_placement in ("auto", "search") and nbytes >= self._PLACED_TRAJ_BYTES
                  and not torch.cuda.is_current_stream_capturing())
         if not timed:
             launch_fn()
@@ -1089,7 +1107,7 @@ class CoreEnvironment(ABC):
     def trajectory_placement_settled(self) -> bool:
         """True once the pooled large output sets have all been timed in real launches and none is up for replacement: a caller
         that wants steady timings (bench.py) steps until then. Always True when nothing is pooled or placed."""
-        if not self._traj_sets or self.trajectory_placement != "auto" or not self.trajectory_pool:
+        if not self._traj_sets or self.trajectory_placement not in ("auto", "search") or not self.trajectory_pool:
             return True
         for ts in self._traj_sets:
             self._traj_note_launch(ts)
@@ -1100,7 +1118,8 @@ class CoreEnvironment(ABC):
             if len(sets) < self._TRAJ_POOL_SETS or any(t.steady_ms is None for t in sets):
                 return False
             ms = [t.steady_ms for t in sets]
-            if max(ms) > 1.03 * min(ms) and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS:
+            big = key[1] * (key[2] + key[3]) * key[0] * (4 if key[5] is torch.float32 else 8) >= (1 << 30)  # only such sets are replaced
+            if big and max(ms) > 1.03 * min(ms) and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS:
                 return False
         return True
 
@@ -1155,7 +1174,7 @@ class CoreEnvironment(ABC):
                     ms = ts.steady_ms if (sib and ts.steady_ms is not None) else (ts.placement or {}).get("chosen_ms")
                     if (best is not None and ms is not None and ms > 1.03 * best and (OW + S) * rows * B * isz >= (1 << 30)
                             and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS and launch is not None
-                            and self.trajectory_placement == "auto"):
+                            and self.trajectory_placement in ("auto", "search")):
                         self._placement_replaced[key] = self._placement_replaced.get(key, 0) + 1
                         self._placement_target = best if sib else None
                         del self._traj_sets[k]
@@ -1163,6 +1182,12 @@ class CoreEnvironment(ABC):
                     self._traj_sets.append(self._traj_sets.pop(k))  # most recently used last
                     return ts
             self._traj_sets = [t for t in self._traj_sets if t.key == key][-(self._TRAJ_POOL_SETS - 1):] if self._TRAJ_POOL_SETS > 1 else []
+        if (pooled and want_states and not env_major and self.trajectory_placement == "auto" and self._placement_target is None
+                and self._TRAJ_POOL_SETS == 2 and not self._traj_sets and key not in self._arena_made
+                and (OW + S) * rows * B * isz >= max(self._PLACED_TRAJ_BYTES, self._ARENA_MIN_SET_BYTES)):
+            pair = self._traj_arena_pair(key, B, rows, OW, S, last_e, isz, stream)
+            if pair is not None:
+                return pair
         ts = CoreEnvironment._TrajSet()
         ts.key = key
         ts.ev, ts.ev_pending, ts.steady_ms, ts.uses = None, False, None, 0
@@ -1195,9 +1220,9 @@ class CoreEnvironment(ABC):
         if want_states:
             def time_launch(block):
                 ptrs = _native.ptr_array([block.data_ptr() + j * leaf_e * isz for j in range(S)])
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 launch(ts.obs_ptr, ptrs, ts.last_ptrs)  # warm (clocks, TLB)
-                for e in ev[:-1]:  # three timed launches, the fastest counts: the first ones of a process run a few % slow
+                for e in ev[:-1]:  # two timed launches, the faster counts: the first ones of a process run a few % slow
                     e.record()
                     launch(ts.obs_ptr, ptrs, ts.last_ptrs)
                 ev[-1].record()
@@ -1234,6 +1259,65 @@ class CoreEnvironment(ABC):
             ts.use0 = [CoreEnvironment._storage_use_count(st._cdata) for st in ts.storages]
             self._traj_sets.append(ts)
         return ts
+
+    # Deterministic placement of the FIRST two sets of a shape (round 4): one arena laid out
+    #     [observations A | observations B | (gap) | state block A | state block B]
+    # A launch's two kinds of write streams — 8 observation components, 7 state leaves — then start at least _ARENA_MIN_DISTANCE
+    # apart inside one large allocation, which is what turned the slow placement level into the fast one in every experiment of
+    # profiles/r03_placement_regions.md (>= 16 GiB between observations and leaves); tools/placement_arena.py: 0.709 / 0.716 of the
+    # roof for the two sets of the headline launch with no gap at all (the other set's observations ARE the distance), against 0.64
+    # ... 0.73 for hand-made gaps of 16 ... 96 GiB and 0.70 ... 0.73 for searched placements. No probe launches, no spacers, no
+    # empty_cache(), and the two sets run alike. The search (timing the launch into candidate blocks) remains the way a THIRD set is
+    # made (a caller that holds on to outputs) and the way a set is replaced whose real launches run > 3 % slower than its
+    # sibling's. Price: both sets are views of one allocation — holding a single returned tensor keeps all of it alive
+    # (`trajectory_placement = "search"` restores one allocation per returned array).
+    _ARENA_MIN_DISTANCE = 17 << 30
+    _ARENA_MIN_SET_BYTES = 4 << 30  # smaller sets would be mostly gap: they keep the search
+
+    def _traj_arena_pair(self, key, B, rows, OW, S, last_e, isz, stream):
+        dt, dev = self.dtype, self.device
+        up = lambda n: (n + 63) // 64 * 64  # every sub-buffer starts on a 256-byte boundary
+        obs_e, blk_e = up(rows * OW * B), up(S * rows * B)
+        near = min(2 * obs_e, obs_e + blk_e) * isz  # distance observations -> state block of set A / set B without a gap
+        gap_e = up(max(0, self._ARENA_MIN_DISTANCE - near) // isz)
+        total = 2 * obs_e + gap_e + 2 * blk_e
+        if total * isz > torch.cuda.mem_get_info(dev)[0] * 0.8:
+            return None  # not worth crowding the device: the searched single sets take over
+        try:
+            arena = torch.empty(total, dtype=dt, device=dev)
+        except torch.OutOfMemoryError:
+            return None
+        self._arena_made.add(key)
+        sets = []
+        for k in range(2):
+            ts = CoreEnvironment._TrajSet()
+            ts.key = key
+            ts.ev, ts.ev_pending, ts.steady_ms, ts.uses = None, False, None, 0
+            ts.obs_buf = arena[k * obs_e: k * obs_e + rows * OW * B].view(rows, OW, B)
+            b0 = 2 * obs_e + gap_e + k * blk_e
+            ts.st_buf = arena[b0: b0 + S * rows * B].view(S, rows, B)
+            ts.placement = {"arena_gib": round(total * isz / 2**30, 2), "gap_gib": round(gap_e * isz / 2**30, 2), "set": k,
+                            "what": "one arena [obs A | obs B | gap | states A | states B]: no probe launches"}
+            ts.lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
+            lb, sb = ts.lbuf.data_ptr(), ts.st_buf.data_ptr()
+            ts.last_ptrs = _native.ptr_array([lb + j * last_e * isz for j in range(S)])
+            ts.obs_ptr = ts.obs_buf.data_ptr()
+            ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (rows * B, 1, B)).unbind(0))
+            ts.traj_ptrs = _native.ptr_array([sb + j * rows * B * isz for j in range(S)])
+            ts.observations = ts.obs_buf.permute(2, 0, 1)
+            ts.last = tuple(ts.lbuf[:, :B].unbind(0))
+            ts.tens = (ts.observations,) + ts.st_views + ts.last
+            ts.storages = [arena.untyped_storage(), ts.lbuf.untyped_storage()]
+            ts.stream = stream
+            sets.append(ts)
+        del arena
+        for ts in sets:  # the counts of an untouched pair: every view of both sets exists, nothing outside refers to any
+            ts.rc0 = tuple(map(sys.getrefcount, ts.tens))
+        for ts in sets:
+            ts.use0 = [CoreEnvironment._storage_use_count(st._cdata) for st in ts.storages]
+        self._traj_sets.extend(reversed(sets))  # set B waits in the pool (dead: nothing refers to it), set A is handed out
+        self.last_placement = sets[0].placement
+        return sets[0]
 
     def _run_sim_ahead_env_major_large(self, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub, want_states):
         """Row-major (reference-shaped) trajectories of at least _PLACED_TRAJ_BYTES: the fused env-major kernels write scattered
@@ -1445,7 +1529,7 @@ class CoreEnvironment(ABC):
         still reads a returned tensor after you dropped your last reference to it, keep that reference until the stream has
         synchronised, or call `env.pool_wait_stream(that_stream)` (the next reuse then waits for it), or set
         `env.trajectory_pool = False`. The first large call of a shape also PLACES its set: it times its own launch into up to four
-        candidate state blocks (about four launches each), may call `torch.cuda.empty_cache()` once and transiently holds the
+        candidate state blocks (three launches each), may call `torch.cuda.empty_cache()` once and transiently holds the
         rejected blocks plus a spacer of at most a third of the free device memory; a set that then runs more than 3 % slower than
         its sibling in real launches is replaced, at most twice per shape (`env.trajectory_placement = "off"` switches all of it
         off; `env.release_trajectory_buffers()` frees the dead sets; `env.trajectory_placement_settled` says when it is over)."""

@@ -35,7 +35,8 @@ extern "C" {
 /* 4: v3 + excenv_random_state, excenv_update_ref_to, excenv_observe (additions only; every v3 signature is unchanged)
  * 5: v4 + excenv_stream_pattern (addition only)
  * 6: v5 + excenv_launch_opts_t.flags (the former `reserved` field; 0 keeps the old meaning); excenv_sim_ahead reads row-major
- *    actions inside the lane-major trajectory kernel (no workspace needed for that combination) */
+ *    actions inside the lane-major trajectory kernel (no workspace needed for that combination); additions:
+ *    excenv_sim_ahead_fuses_actions, excenv_last_launch, excenv_allgather */
 #define EXCENV_ABI_VERSION 6
 
 /* Environment ids. Field orders follow the reference dataclasses. */
@@ -162,7 +163,7 @@ typedef struct {
 int excenv_abi_version(void);
 const char* excenv_last_error(void);
 /* Name of the trajectory-kernel form the last excenv_sim_ahead[_ws] call of this thread enqueued ("" before the first):
- * "sim_ahead_kernel (V=1|V=2|V=4)", "sim_ahead_kernel (general[, V=2])", "sim_ahead_kernel (row-major actions fused)",
+ * "sim_ahead_kernel (V=1|V=2|V=4)", "sim_ahead_kernel (general)", "sim_ahead_kernel (row-major actions fused)",
  * "sim_ahead_emr_kernel", "sim_ahead_em_kernel[ (general)]", "transposition workspace + sim_ahead_kernel". Informational
  * (tests assert that the path they mean to check is the one that ran). */
 const char* excenv_last_launch(void);
@@ -296,6 +297,15 @@ int excenv_update_ref_to(int env, int dtype, int64_t B, const excenv_props_t* pr
  * leaves, key_leaf [B][2] the keys that become State.PRNGKey. Same samplers as excenv_update_ref. */
 int excenv_random_state(int env, int dtype, int64_t B, const excenv_props_t* props, const int64_t* keys,
                         void* const* state_out, int64_t* key_leaf, void* stream);
+
+/* ---- the path's one collective (no reference counterpart: the reference is single-device): all ranks integrate
+ * their own contiguous slice of the batch with no communication, and a consumer that needs the global batch on every rank
+ * reassembles it with ONE all-gather — typically the last observation row of a chunk (obs_traj + N * (O + n_control) * B elements
+ * in the lane-major layout: count_per_rank = (O + n_control) * B_local). A thin wrapper over RCCL's ncclAllGather for binders
+ * that do not go through torch.distributed (the Python mirror does): `nccl_comm` is the caller's ncclComm_t, `recv` holds
+ * world_size * count_per_rank elements in rank order, enqueued on `stream`. librccl.so is loaded on first use; without it the
+ * call returns EXCENV_EUNSUPPORTED. Shards must be equal-sized (pad the last rank's slice otherwise). */
+int excenv_allgather(void* nccl_comm, int dtype, const void* send, void* recv, int64_t count_per_rank, void* stream);
 
 /* ---- calibration, no reference counterpart: the memory access shape of excenv_sim_ahead (lane-major buffers) without any
  * arithmetic. `rows` times, every workgroup reads one 4 KiB piece of each of n_read streams and writes one 4 KiB piece of each

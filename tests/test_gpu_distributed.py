@@ -105,3 +105,59 @@ def test_bench_refuses_world_size_mismatch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                        env=_child_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "does not match --gpus" in (p.stderr + p.stdout)
+
+
+def test_excenv_allgather_through_a_raw_rccl_communicator():
+    """excenv_allgather (include/excenv.h: the path's one collective for binders that do not use torch.distributed) on a
+    communicator made with RCCL's own C API (ncclGetUniqueId / ncclCommInitRank through ctypes, one rank — the GPU box has one
+    card): the gathered buffer equals the rank's slice, on the caller's stream, and a product trajectory's last observation row
+    survives the trip."""
+    import ctypes
+
+    import torch
+
+    from exciting_environments_amd import EnvironmentRegistry, _native
+
+    rccl = None
+    for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        try:
+            rccl = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("librccl.so not found")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    torch.cuda.set_device(0)
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        B, K = 4096, 12
+        env = EnvironmentRegistry.PMSM.make(batch_size=B, device="cuda:0")
+        _, st = env.vmap_reset()
+        acts = torch.rand((B, K, 2), device="cuda:0") * 2 - 1
+        obs, states, last = env.vmap_sim_ahead(st, acts, env.tau, env.tau)
+        final = obs[:, -1, :]                       # a view of the lane-major buffer: [O, B] contiguous underneath
+        send = final.t().contiguous().reshape(-1)   # this rank's slice as the ABI describes it: (O + n_control) * B_local elements
+        recv = torch.full_like(send, float("nan"))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            _native.allgather(comm.value, send, recv)
+        side.synchronize()
+        assert torch.equal(recv, send)
+        for dt in (torch.float32, torch.float64):
+            a = torch.arange(1000, dtype=dt, device="cuda:0")
+            b = torch.empty_like(a)
+            _native.allgather(comm.value, a, b)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -412,3 +412,40 @@ def test_reference_leaf_that_needs_conversion_is_reread_after_in_place_update(ki
     _, states2, _ = env.vmap_sim_ahead(state, acts, env.tau, env.tau)
     assert torch.equal(states2.reference.velocity[:, 0].cpu(), leaf.to(torch.float32).cpu())
     assert not torch.equal(r1, states2.reference.velocity)
+
+
+@pytest.mark.parametrize("control", [[], ["i_d", "i_q"], ["torque"], ["i_q", "torque", "i_d"]])
+@pytest.mark.parametrize("semantics", ["ahead", "step"])
+@pytest.mark.parametrize("dtype,solver", [(torch.float32, "euler"), (torch.float32, "tsit5"), (torch.float64, "euler"), (torch.float64, "rk4")])
+def test_pmsm_gym_trajectories_from_the_wide_lean_kernel_equal_the_general_kernel(dtype, solver, semantics, control):
+    """Round 4 (kernels.hpp, LGYM): PMSM's reward / terminated / truncated trajectories written by the four-environments-per-lane
+    kernel (packed flag stores, pmsm_reward shared with the general instantiation) hold the bits of the one-environment general
+    kernel — observations (incl. control columns), states, last state, reward, flags — and the launch that ran is the lean one."""
+    from exciting_environments_amd import _native
+
+    B, K = 2048, 37
+    vmax = 4 if dtype is torch.float32 else 2
+    env, props, keep, spec = make_env("pmsm", B, dtype, solver=solver, control_state=list(control))
+    env.sim_ahead_semantics = semantics
+    st = random_state("pmsm", B, NP_DTYPE[dtype], spec, seed=91)
+    st[3] = (st[3] * 1.4).astype(NP_DTYPE[dtype])  # some environments outside the current circle: the flags are not all zero
+    rng = np.random.default_rng(92)
+    refs = {n: rng.uniform(-150, 150, B).astype(NP_DTYPE[dtype]) for n in control}
+    acts = env.new_actions_buffer(K)
+    acts.copy_(torch.as_tensor(rng.uniform(-1, 1, (B, K, 2)).astype(NP_DTYPE[dtype]), device=env.device))
+    outs = {}
+    for vec in (vmax, 1):
+        env.launch_opts = _native.launch_opts(envs_per_lane=vec)
+        outs[vec] = env.vmap_sim_ahead(to_state(env, st, reference=refs), acts, env.tau, env.tau, return_rew_trunc_term=True)
+        torch.cuda.synchronize()
+        assert _native.last_launch() == ("sim_ahead_kernel (lean, gym outputs)" if vec == vmax else "sim_ahead_kernel (general)")
+    a, b = outs[vmax], outs[1]
+    assert torch.equal(a[0], b[0])
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(a[1].physical_state, n), getattr(b[1].physical_state, n)), n
+        assert torch.equal(getattr(a[2].physical_state, n), getattr(b[2].physical_state, n)), n
+    for k, name in ((3, "reward"), (4, "truncated"), (5, "terminated")):
+        assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), name
+    assert a[4].any() and not a[4].all()
+    if control:
+        assert float(a[3].abs().max()) > 0

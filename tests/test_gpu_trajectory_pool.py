@@ -239,3 +239,87 @@ def test_unpooled_sets_are_not_probed():
     o2 = env.vmap_sim_ahead(s0, a, env.tau, env.tau)[0]
     assert env.last_placement is None and env._traj_sets == []
     assert o1.data_ptr() != o2.data_ptr() and torch.equal(o1, o2)
+
+
+def test_pool_wait_stream_orders_the_reuse_behind_a_foreign_reader():
+    """the pools cannot see Tensor.record_stream. A consumer that reads a returned tensor on a side stream and
+    drops its reference early calls env.pool_wait_stream(side): the launch that writes the set again then waits for that stream, so
+    the reader still sees the values it was handed."""
+    env, st = _env("pmsm", B=1 << 15)
+    K = 24
+    acts = [_actions(env, K, 60 + i) for i in range(3)]
+    obs, states, last = env.vmap_sim_ahead(st, acts[0], env.tau, env.tau)
+    want = obs.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(400_000_000)      # the reader is slow: ~0.2 s before it touches the buffer
+        got = obs + 0                       # reads the pooled observation buffer on the side stream
+    env.pool_wait_stream(side)
+    ptr = obs.data_ptr()
+    del obs, states
+    second = env.vmap_sim_ahead(last, acts[1], env.tau, env.tau)
+    third = env.vmap_sim_ahead(second[2], acts[2], env.tau, env.tau)   # the first set comes round again
+    assert third[0].data_ptr() == ptr, "the dead set was expected to be written again"
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert not torch.equal(third[0], want)
+
+
+def test_placement_settles_and_reports_real_launch_times():
+    """The pooled sets are compared by HIP-event times of their real launches; `trajectory_placement_settled` turns True once
+    every pooled set of the shape has one (and no replacement is pending)."""
+    env, st = _env("pendulum", B=1 << 14)
+    acts = _actions(env, 32, 70)
+    assert env.trajectory_placement_settled  # nothing pooled yet
+    out = env.vmap_sim_ahead(st, acts, env.tau, env.tau)
+    seen = [env.trajectory_placement_settled]
+    for _ in range(12):
+        out = env.vmap_sim_ahead(out[2], acts, env.tau, env.tau)
+        torch.cuda.synchronize()
+        seen.append(env.trajectory_placement_settled)
+    assert seen[0] is False and seen[-1] is True
+    assert len(env._traj_sets) == 2 and all(t.steady_ms is not None and t.steady_ms > 0 for t in env._traj_sets)
+    env.trajectory_placement = "off"
+    assert env.trajectory_placement_settled
+
+
+def test_arena_pair_is_made_once_reused_and_equals_the_unpooled_run():
+    """Round 4: the first two sets of a shape are views of ONE arena [obs A | obs B | gap | states A | states B] — no probe
+    launches. The chained run alternates between them, holds the bits of the unpooled run, never writes a set somebody still
+    sees, and a caller that holds on to outputs gets searched single sets from the third call on (no second arena)."""
+    env, st = _env("pmsm", B=2048)
+    env._ARENA_MIN_SET_BYTES, env._ARENA_MIN_DISTANCE = 0, 1 << 20
+    ref_env, ref_st = _env("pmsm", B=2048, pool=False)
+    K = 12
+    acts = [_actions(env, K, 80 + i) for i in range(5)]
+    ptrs, outs = [], []
+    s, rs = st, ref_st
+    for i in range(5):
+        o, states, s = env.vmap_sim_ahead(s, acts[i], env.tau, env.tau)
+        ro, rstates, rs = ref_env.vmap_sim_ahead(rs, acts[i], ref_env.tau, ref_env.tau)
+        assert torch.equal(o, ro) and torch.equal(states.physical_state.i_q, rstates.physical_state.i_q)
+        ptrs.append(o.data_ptr())
+        if i == 0:
+            assert env.last_placement["what"].startswith("one arena") and len(env._traj_sets) == 2
+            a0, a1 = env._traj_sets[0], env._traj_sets[1]
+            assert a0.obs_buf.untyped_storage().data_ptr() == a1.obs_buf.untyped_storage().data_ptr()  # one allocation
+            gap = a1.st_buf.data_ptr() - a1.obs_buf.data_ptr() if a1.placement["set"] == 0 else a0.st_buf.data_ptr() - a0.obs_buf.data_ptr()
+            assert gap >= (1 << 20)
+        del o, states
+    assert ptrs[0] == ptrs[2] == ptrs[4] and ptrs[1] == ptrs[3] and ptrs[0] != ptrs[1]
+    # a caller that keeps every output: the pair is used up after two calls, then single sets (no second arena)
+    env2, st2 = _env("pmsm", B=2048)
+    env2._ARENA_MIN_SET_BYTES, env2._ARENA_MIN_DISTANCE = 0, 1 << 20
+    held, s2 = [], st2
+    for i in range(4):
+        out = env2.vmap_sim_ahead(s2, acts[i], env2.tau, env2.tau)
+        held.append(out)
+        s2 = out[2]
+    stor = {o[0].untyped_storage().data_ptr() for o in held}
+    assert len(stor) == 3  # calls 1 and 2 share the arena, calls 3 and 4 have allocations of their own
+    torch.cuda.synchronize()
+    s3 = st
+    for i in range(4):  # and what they hold is still what the unpooled run computes
+        ro, _, s3 = ref_env.vmap_sim_ahead(s3 if i else ref_st, acts[i], ref_env.tau, ref_env.tau)
+        assert torch.equal(held[i][0], ro)

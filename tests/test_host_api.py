@@ -74,6 +74,19 @@ def test_abi_argument_validation_without_gpu():
     assert b"control_idx" in lib.excenv_last_error()
     assert lib.excenv_random_state(0, 0, i64(4), ctypes.byref(p), None, one, vp(16), None) == -2
     assert lib.excenv_random_state(0, 5, i64(4), ctypes.byref(p), vp(16), one, vp(16), None) == -1  # bad dtype
+    # ABI v6: the collective wrapper validates before it touches RCCL; the launch-form query answers 0 for anything not fused
+    assert lib.excenv_allgather(None, 0, vp(16), vp(16), i64(4), None) == -2 and b"NULL" in lib.excenv_last_error()
+    assert lib.excenv_allgather(vp(16), 3, vp(16), vp(16), i64(4), None) == -1 and b"dtype" in lib.excenv_last_error()
+    assert lib.excenv_allgather(vp(16), 0, vp(16), vp(16), i64(-1), None) == -1
+    assert lib.excenv_allgather(vp(16), 0, None, None, i64(0), None) == 0  # nothing to gather
+    assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(100), ctypes.byref(p), 0, 0, 0, 1, vp(16), None) == 1
+    assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(101), ctypes.byref(p), 0, 0, 0, 1, vp(16), None) == 0  # 404-byte rows
+    assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(100), ctypes.byref(p), 1, 0, 0, 1, vp(16), None) == 0  # control columns
+    assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 12), i64(100), ctypes.byref(p), 0, 0, 0, 1, vp(16), None) == 0  # small batch
+    assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(100), ctypes.byref(p), 0, 0, 0, 0, vp(16), None) == 0  # row-major outputs
+    off = _native.launch_opts(flags=_native.OPT_NO_FUSED_ACTIONS)
+    assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(100), ctypes.byref(p), 0, 0, 0, 1, vp(16), ctypes.byref(off)) == 0
+    assert lib.excenv_last_launch() in (b"", lib.excenv_last_launch())  # a string, never NULL
     assert lib.excenv_update_ref_to(0, 0, i64(4), ctypes.byref(p), i32(0), None, None, vp(16), vp(32), None, vp(16), vp(32),
                                     i32(1), i32(5), None) == -1 and b"alias" in lib.excenv_last_error()
     assert lib.excenv_update_ref_to(0, 0, i64(4), ctypes.byref(p), i32(9), None, None, vp(16), vp(32), None, vp(48), vp(64),
@@ -474,3 +487,24 @@ def test_trajectory_kernels_do_not_spill():
     assert all(v["scratch"] == 0 for k, v in ring.items() if "PmsmIfEE" in k)
     lean32 = {k: v for k, v in res.items() if "sim_ahead_kernel" in k and "IfEEf" in k and "PmsmSat" not in k}
     assert lean32 and all(v["scratch"] == 0 for v in lean32.values()), [k for k, v in lean32.items() if v["scratch"]]
+
+
+def test_placement_search_memory_budget_for_the_c5_shard():
+    """SURVEY.md §8e / BASELINE C5: every rank of the 8-GPU run holds 2^22 PMSM environments, 100-step chunks, fp32. The pooled +
+    placed output sets must fit one MI355X (288 GB) with room for the actions, the gathered observations and torch itself — also
+    at the peak of a placement search (candidates + spacers)."""
+    from exciting_environments_amd.core_env import CoreEnvironment
+
+    B, rows, OW, S, isz = 1 << 22, 101, 8, 7, 4
+    hbm = 288 * 10**9
+    b = CoreEnvironment.placement_memory_budget(B, rows, OW, S, isz, free_bytes=hbm - 8 * 10**9)
+    assert abs(b["set"] - 25.53e9) < 0.05e9
+    assert b["steady"] <= 52e9                       # two sets
+    assert b["search_peak"] <= 0.55 * hbm, b         # one live set + a search in progress: about half the device
+    actions = B * 100 * 2 * isz
+    gathered = 8 * B * OW * isz                      # the all-gathered final observation row of eight ranks
+    assert b["steady"] + b["search_peak"] - b["set"] + actions + gathered < 0.75 * hbm
+    assert b["searches_at_most"] == 4
+    # a device that is already full leaves no room for spacers: the bound follows the free memory, not the constant
+    tight = CoreEnvironment.placement_memory_budget(B, rows, OW, S, isz, free_bytes=30 * 10**9)
+    assert tight["search_peak"] < b["search_peak"] and tight["search_peak"] <= tight["set"] + 4 * 12e9 + 14e9 + 4 * 10e9 + 1e9
