@@ -281,8 +281,9 @@ def measure_traffic_live(args):
                     if row.get("Counter_Name") != counter:
                         continue
                     per_kernel.setdefault(row.get("Kernel_Name", ""), []).append(float(row.get("Counter_Value", 0) or 0))
-            hk = [v for k, v in per_kernel.items() if hot in k]
-            ck = [v for k, v in per_kernel.items() if "trunc" in k.lower()]
+            # the matching kernel with the most dispatches (several instantiations can share the name's stem)
+            hk = sorted((v for k, v in per_kernel.items() if hot in k), key=len, reverse=True)
+            ck = sorted((v for k, v in per_kernel.items() if "trunc" in k.lower()), key=len, reverse=True)
             if r.returncode != 0 or not hk:
                 return None, f"rocprofv3 --pmc {counter} pass gave no {hot} dispatch (rc {r.returncode})"
             vals[counter] = float(np.mean(hk[0]))                      # KiB per dispatch
@@ -291,11 +292,18 @@ def measure_traffic_live(args):
         return None, f"live PMC passes failed: {type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    # corrections from the calibration copy of the SAME passes (a 1 GiB coalesced read + write): the guide's gfx950 behaviour is
+    # FETCH_SIZE = 0.5 x, WRITE_SIZE = 1.0 x; anything else (another ROCm, another counter definition) is not silently trusted
+    cf, cw = calib.get("FETCH_SIZE"), calib.get("WRITE_SIZE")
+    if cf is None or cw is None or abs(cf - 0.5) > 0.025 or abs(cw - 1.0) > 0.05:
+        return None, f"calibration copy reads FETCH_SIZE {cf} x / WRITE_SIZE {cw} x its bytes (expected 0.5 / 1.0): counters not trusted"
+    hbm = (vals["FETCH_SIZE"] / cf + vals["WRITE_SIZE"] / cw) * 1024.0
     desc = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes (separate child processes, before the timed "
             f"process touched the GPU) over tools/traffic_probe.py; per launch of {hot}: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB "
-            f"(x2, gfx950 correction), WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB; calibration copy of the same passes: FETCH_SIZE "
-            f"reports {calib['FETCH_SIZE']} x the bytes read, WRITE_SIZE {calib['WRITE_SIZE']} x the bytes written")
+            f"(/ {cf:.4f}, the factor the calibration copy of the same pass reads), WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB (/ {cw:.4f})")
+    if args.action_layout == "env_major":
+        desc += ("; row-major actions are read as 64-byte windows (DESIGN.md §4.1b): for those requests the factor is an upper bound "
+                 f"(they are tallied at 64 bytes each; lower bound of the traffic {(vals['FETCH_SIZE'] + vals['WRITE_SIZE'] / cw) * 1024.0:.4e} B)")
     return hbm, desc
 
 
@@ -439,9 +447,9 @@ def main():
             gathered = gatherer.start(final_row(obs), gathered)
         return last
 
-    # set-up: the first calls create (and place) the pooled output sets of the trajectory path; with fewer than four warm-up
+    # set-up: the first calls create (and place) the pooled output sets of the trajectory path; with fewer than six warm-up
     # steps they are made here, outside warm-up and timed region alike
-    setup_steps = max(0, 6 - args.warmup) if args.path != "step" else 0
+    setup_steps = max(0, 6 - args.warmup) if args.path != "step" else 0  # with fewer than six warm-up steps: this many extra, untimed
     for _ in range(setup_steps):
         state = one_step(state)
     # the pooled output sets are compared by the times of their real launches and a clearly slower one is replaced (core_env.py,

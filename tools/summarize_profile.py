@@ -128,6 +128,14 @@ if any(pmc.values()):
         hbm = (2.0 * hot[0] + hot[1]) * 1024.0
         lines += [f"`{hot[2][:60]}...`: HBM traffic per launch = (2 x {hot[0]:.0f} KiB + {hot[1]:.0f} KiB) x 1024 "
                   f"= {hbm:.4e} bytes.", ""]
+        if "rowmajor" in tag or "_em_" in tag:
+            lo = (1.0 * hot[0] + hot[1]) * 1024.0
+            lines += ["Caveat for this kernel: the x2 is calibrated on wide coalesced reads (128-byte fabric requests tallied at 64 "
+                      "bytes). The row-major action array is read as 64-byte windows, four adjacent lanes per window "
+                      "(DESIGN.md §4.1b): FETCH_SIZE / 64 B is then the number of fabric requests, one per 128-byte line a window "
+                      "touches, and what a request moves is 64 bytes if the L2 fills sectors and 128 if it fills lines (part of the "
+                      f"second requests of a line are Infinity-Cache hits, which the counter includes). Bounds: {lo:.4e} ... "
+                      f"{hbm:.4e} bytes per launch.", ""]
         if key:
             tpath = os.path.join(dst, "traffic.json")
             tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
