@@ -390,12 +390,10 @@ int excenv_random_state(int env, int dtype, int64_t B, const excenv_props_t* pro
 // single-GPU users of libexcenv_hip.so do not need it; the communicator is the caller's.
 namespace {
 typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
-nccl_allgather_fn resolve_allgather(const char** why) {
-  static nccl_allgather_fn fn = nullptr;
-  static const char* err = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+struct RcclEntry {
+  nccl_allgather_fn fn = nullptr;
+  const char* err = nullptr;
+  RcclEntry() {
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* h = nullptr;
     for (const char* n : names) {
@@ -408,8 +406,11 @@ nccl_allgather_fn resolve_allgather(const char** why) {
       if (!fn) err = "librccl.so has no ncclAllGather";
     }
   }
-  if (why) *why = err;
-  return fn;
+};
+nccl_allgather_fn resolve_allgather(const char** why) {
+  static const RcclEntry entry;  // initialised once, thread-safely (C++11 function-local static); read-only afterwards
+  if (why) *why = entry.err;
+  return entry.fn;
 }
 }  // namespace
 
