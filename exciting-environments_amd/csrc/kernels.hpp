@@ -416,11 +416,13 @@ constexpr int AEM_BLOCK_BYTES = 1024 + 16;  // one LDS-direct load instruction's
 template <class M> constexpr int aem_np() { return M::ID == EXCENV_ACROBOT ? 2 : EXCENV_AEM_NP; }
 template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return (size_t)(BLOCK / 64) * V * aem_np<M>() * AEM_BLOCK_BYTES; }
 
-// LGYM (round 4; PMSM, lean, V * sizeof(T) == 16): the reward / terminated / truncated trajectories of core_env.py:490-531 written by
-// the wide kernel itself — PMSM's reward (pmsm_env.py:985-1037) needs three references per environment and ~40 instructions, its
-// flags are one byte each (|i_dq| > 1), so the four environments of a lane add a 16-byte reward store and two packed 4-byte flag
-// stores per row. The general instantiation (one environment per lane, byte stores) took 6.8 ms for the launch the lean kernel
-// does in 4.8; the other models' rewards (two sin / cos pairs per controlled angle, up to eight controls) stay there.
+// LGYM (round 4; lean, V * sizeof(T) == 16, not the look-up model): the reward / terminated / truncated trajectories of
+// core_env.py:490-531 written by the wide kernel itself. PMSM (pmsm_env.py:972-1037): three references per environment, ~40
+// instructions, one flag byte (|i_dq| > 1) — one 16-byte reward store and two packed 4-byte flag stores per row of the lane's four
+// environments. The other models (e.g. pendulum_env.py:297-309, 381-390): control_state is a subset of the S state fields, what
+// depends on the references alone is computed once per trajectory, per row one sin / cos per controlled ANGLE and environment, and
+// O + n_control packed flag stores. The general instantiation (one environment per lane, byte stores, the reward loop unrolled over
+// eight possible controls) took 7.5 ms (PMSM) / 4.5 ms (pendulum) for launches the lean kernels do in 4.9 / 1.6.
 template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false, bool LGYM = false>
 __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
@@ -430,7 +432,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   // outputs' code out where none are asked for (STATES == -2): 0.569 -> 0.60 of the roof, the lean one-environment form's level.
   static_assert(!(GENERAL && V > 1), "per-environment property sets: one environment per lane");
   static_assert(GENERAL == (STATES < 0), "STATES -1 / -2 (general, with / without the gym outputs' code) and 0 / 1 (lean)");
-  static_assert(!LGYM || (!GENERAL && M::IS_PMSM && !M::HAS_LUT && aem_shape_ok<T, V>()), "lean gym outputs: PMSM, widest lean form");
+  static_assert(!LGYM || (!GENERAL && !M::HAS_LUT && aem_shape_ok<T, V>()), "lean gym outputs: widest lean form, no look-up model");
   constexpr int NC = GENERAL ? V : 1;  // property sets per lane
   constexpr bool GYM = GENERAL && STATES == -1;
   static_assert(!AEM || (!GENERAL && !M::HAS_LUT && aem_shape_ok<T, V>() && (16 / (int)sizeof(T)) % A == 0),
@@ -470,10 +472,47 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
       aux[v].prev_clip[1] = st[v][1];
     }
   }
-  // LGYM: the references of the controlled fields among i_d (3), i_q (4), torque (5), per environment of the lane
+  // LGYM, the other models (pendulum_env.py:297-309, 381-390 and the like): control_state is a subset of the S state fields, so at
+  // most NCM = S controls. Everything that depends on a reference only — sin / cos of a controlled angle's reference or the
+  // normalised reference of any other field, and the (constant) truncated flag of its observation column — is computed once per
+  // trajectory with the functions the general instantiation calls per row: same values, same bits.
+  constexpr int NCM = (LGYM && !M::IS_PMSM) ? S : 1;
+  T gp_a[V][NCM], gp_b[V][NCM];
+  uint8_t gp_f[V][NCM];
+  if constexpr (LGYM && !M::IS_PMSM) {
+#pragma unroll
+    for (int j = 0; j < NCM; ++j) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        gp_a[v][j] = gp_b[v][j] = T(0);
+        gp_f[v][j] = 0;
+      }
+      if (j < ka.n_control) {
+        const int f = ka.control_idx[j];
+        T lo = c.smin[0], hi = c.smax[0];
+        bool ang = false;
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+          lo = (f == q) ? c.smin[q] : lo;
+          hi = (f == q) ? c.smax[q] : hi;
+          ang = ang || (is_angle_field<M>(q) && f == q);
+        }
+        T tmp[V];
+        load_v<T, V>(ka.reference[j] + blk0 + lane_env, tmp);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const T nr = normalize(tmp[v], lo, hi);
+          gp_f[v][j] = xabs(nr) > T(1);
+          if (ang) sincos_t(tmp[v], gp_a[v][j], gp_b[v][j]);
+          else gp_a[v][j] = nr;
+        }
+      }
+    }
+  }
+  // LGYM, PMSM: the references of the controlled fields among i_d (3), i_q (4), torque (5), per environment of the lane
   T g_id[V], g_iq[V], g_tq[V];
   bool has_id = false, has_iq = false, has_tq = false;
-  if constexpr (LGYM) {
+  if constexpr (LGYM && M::IS_PMSM) {
 #pragma unroll
     for (int v = 0; v < V; ++v) g_id[v] = g_iq[v] = g_tq[v] = T(0);
 #pragma unroll
@@ -588,7 +627,64 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
         store_stream<T, V>(ka.straj[j] + s_blk + n * ka.s_sk + s_lane, tmp);
       }
     }
-    if constexpr (LGYM) {  // the same outputs for the V environments of a lane: truncated row n, reward / terminated row n - 1
+    if constexpr (LGYM && !M::IS_PMSM) {  // generate_reward / generate_truncated / generate_terminated of the other models, V wide
+      const int64_t e0 = blk0 + lane_env;
+      uint8_t* trow = ka.truncated + n * ka.t_sk + e0;
+      T rew[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) rew[v] = T(0);
+#pragma unroll
+      for (int j = 0; j < NCM; ++j) {
+        if (j < ka.n_control) {
+          const int f = ka.control_idx[j];
+          bool ang = false;
+#pragma unroll
+          for (int q = 0; q < S; ++q) ang = ang || (is_angle_field<M>(q) && f == q);
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            T x, lo, hi;
+            pick_field<M, T>(sv[v], c, f, x, lo, hi);
+            if (ang) {
+              T sx, cx;
+              sincos_t(x, sx, cx);
+              const T ds = sx - gp_a[v][j], dc = cx - gp_b[v][j];
+              rew[v] = rew[v] + -(ds * ds + dc * dc);
+            } else {
+              const T d = normalize(x, lo, hi) - gp_a[v][j];
+              rew[v] = rew[v] + -(d * d);
+            }
+          }
+        }
+      }
+      uint8_t fl[V];
+      if constexpr (M::ID == EXCENV_FLUID_TANK) {  // fluid_tank_env.py:325-333: constants
+#pragma unroll
+        for (int v = 0; v < V; ++v) fl[v] = 0;
+        store_flags<V>(trow, fl);
+      } else {
+#pragma unroll
+        for (int q = 0; q < O; ++q) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) fl[v] = xabs(ob[v][q]) > T(1);
+          store_flags<V>(trow + q * ka.t_sc, fl);
+        }
+#pragma unroll
+        for (int j = 0; j < NCM; ++j) {
+          if (j < ka.n_control) {  // the control columns' flags do not change along the trajectory
+#pragma unroll
+            for (int v = 0; v < V; ++v) fl[v] = gp_f[v][j];
+            store_flags<V>(trow + (O + j) * ka.t_sc, fl);
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) fl[v] = rew[v] == T(0);  // generate_terminated: reward == 0
+      }
+      if (n > 0) {
+        store_stream<T, V>(ka.reward + (n - 1) * ka.g_sk + e0, rew);
+        store_flags<V>(ka.terminated + (n - 1) * ka.g_sk + e0, fl);
+      }
+    }
+    if constexpr (LGYM && M::IS_PMSM) {  // the same outputs for the V environments of a lane: truncated row n, reward / terminated row n - 1
       T rew[V];
       uint8_t fl[V];
 #pragma unroll

@@ -365,8 +365,8 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
   sc.lds_pad = (int)lut_lds_bytes<T, M>(ka.kp, (size_t)sc_in.lds_pad);
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
-  if constexpr (M::IS_PMSM && !M::HAS_LUT) {
-    if (lgym) {  // PMSM's gym trajectories out of the widest lean form (V == 16 / sizeof(T), lean_gym_applies)
+  if constexpr (!M::HAS_LUT) {
+    if (lgym) {  // the gym trajectories out of the widest lean form (V == 16 / sizeof(T))
       constexpr int VA = 16 / (int)sizeof(T);
       if (ka.straj[0] == nullptr) EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 0, false, false, true>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
       else EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 1, false, false, true>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
@@ -433,14 +433,16 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   // control_state columns alone (broadcast properties, no gym outputs, lane-major / tiled trajectories) do not need the
   // one-environment-per-lane GENERAL kernel: they are constant along the trajectory and are filled by control_fill_kernel
   // after the lean kernel has written everything else (same bytes, +1 launch, 0.52 -> 0.7 of the HBM roof at B = 2^22)
-  // PMSM's gym trajectories come out of the widest lean form too (kernels.hpp, LGYM) when everything is lane-major, the batch
+  // the gym trajectories come out of the widest lean form too (kernels.hpp, LGYM) when everything is lane-major, the batch
   // runs that form anyway and the flag / reward / reference arrays allow vector accesses
   constexpr int VMAXG = 16 / (int)sizeof(T);
-  bool lean_gym = with_gym && !batched && M::IS_PMSM && !M::HAS_LUT && sc.action_layout == EXCENV_LAYOUT_LANE_MAJOR &&
+  bool lean_gym = with_gym && !batched && !M::HAS_LUT && ka.n_control <= M::S && sc.action_layout == EXCENV_LAYOUT_LANE_MAJOR &&
                   sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR && sc.B > 0 && (sc.B % VMAXG) == 0 &&
                   (sc.vec_pref > 0 ? sc.vec_pref == VMAXG : auto_envs_per_lane(sc.B, VMAXG) == VMAXG) &&
                   aligned16(sc.gym->reward) && ((uintptr_t)sc.gym->terminated % VMAXG) == 0 && ((uintptr_t)sc.gym->truncated % VMAXG) == 0;
   for (int j = 0; lean_gym && j < ka.n_control; ++j) lean_gym = sc.control->reference[j] != nullptr && aligned16(sc.control->reference[j]);
+  // the four-leaf models in fp64 with an RK solver would need more than 256 registers in that form (one wave per SIMD): general
+  if (sizeof(T) == 8 && M::S == 4 && sc.solver != EXCENV_EULER) lean_gym = false;
   bool split_control = !batched && (!with_gym || lean_gym) && ka.n_control > 0 && sc.traj_layout != EXCENV_LAYOUT_ENV_MAJOR &&
                        sc.action_layout != EXCENV_LAYOUT_ENV_MAJOR && sc.B > 0;
   if (split_control) {
