@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 import sys
 import warnings
 from abc import ABC
@@ -1182,10 +1183,11 @@ class CoreEnvironment(ABC):
                     self._traj_sets.append(self._traj_sets.pop(k))  # most recently used last
                     return ts
             self._traj_sets = [t for t in self._traj_sets if t.key == key][-(self._TRAJ_POOL_SETS - 1):] if self._TRAJ_POOL_SETS > 1 else []
-        if (pooled and want_states and not env_major and self.trajectory_placement == "auto" and self._placement_target is None
+        if (pooled and want_states and (not env_major or self._ARENA_ENV_MAJOR) and self.trajectory_placement == "auto"
+                and self._placement_target is None
                 and self._TRAJ_POOL_SETS == 2 and not self._traj_sets and key not in self._arena_made
                 and (OW + S) * rows * B * isz >= max(self._PLACED_TRAJ_BYTES, self._ARENA_MIN_SET_BYTES)):
-            pair = self._traj_arena_pair(key, B, rows, OW, S, last_e, isz, stream)
+            pair = self._traj_arena_pair(key, B, rows, OW, S, last_e, isz, stream, env_major)
             if pair is not None:
                 return pair
         ts = CoreEnvironment._TrajSet()
@@ -1274,10 +1276,13 @@ class CoreEnvironment(ABC):
     _ARENA_MIN_DISTANCE = 17 << 30
     _ARENA_MIN_SET_BYTES = 4 << 30  # smaller sets would be mostly gap: they keep the search
 
-    def _traj_arena_pair(self, key, B, rows, OW, S, last_e, isz, stream):
+    _ARENA_ENV_MAJOR = os.environ.get("EXCENV_EM_ARENA", "1") != "0"  # row-major (reference-shaped) sets take the arena too
+
+    def _traj_arena_pair(self, key, B, rows, OW, S, last_e, isz, stream, env_major=False):
         dt, dev = self.dtype, self.device
         up = lambda n: (n + 63) // 64 * 64  # every sub-buffer starts on a 256-byte boundary
-        obs_e, blk_e = up(rows * OW * B), up(S * rows * B)
+        leaf_e = (rows * B * isz + 127) // 128 * 128 // isz if env_major else rows * B  # elements between consecutive leaves
+        obs_e, blk_e = up(rows * OW * B), up(S * leaf_e)
         near = min(2 * obs_e, obs_e + blk_e) * isz  # distance observations -> state block of set A / set B without a gap
         gap_e = up(max(0, self._ARENA_MIN_DISTANCE - near) // isz)
         total = 2 * obs_e + gap_e + 2 * blk_e
@@ -1293,18 +1298,22 @@ class CoreEnvironment(ABC):
             ts = CoreEnvironment._TrajSet()
             ts.key = key
             ts.ev, ts.ev_pending, ts.steady_ms, ts.uses = None, False, None, 0
-            ts.obs_buf = arena[k * obs_e: k * obs_e + rows * OW * B].view(rows, OW, B)
+            ts.obs_buf = arena[k * obs_e: k * obs_e + rows * OW * B].view((B, rows, OW) if env_major else (rows, OW, B))
             b0 = 2 * obs_e + gap_e + k * blk_e
-            ts.st_buf = arena[b0: b0 + S * rows * B].view(S, rows, B)
+            ts.st_buf = arena[b0: b0 + S * leaf_e].view((S, leaf_e) if env_major else (S, rows, B))
             ts.placement = {"arena_gib": round(total * isz / 2**30, 2), "gap_gib": round(gap_e * isz / 2**30, 2), "set": k,
                             "what": "one arena [obs A | obs B | gap | states A | states B]: no probe launches"}
             ts.lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
             lb, sb = ts.lbuf.data_ptr(), ts.st_buf.data_ptr()
             ts.last_ptrs = _native.ptr_array([lb + j * last_e * isz for j in range(S)])
             ts.obs_ptr = ts.obs_buf.data_ptr()
-            ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (rows * B, 1, B)).unbind(0))
-            ts.traj_ptrs = _native.ptr_array([sb + j * rows * B * isz for j in range(S)])
-            ts.observations = ts.obs_buf.permute(2, 0, 1)
+            if env_major:
+                ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (leaf_e, rows, 1)).unbind(0))
+                ts.observations = ts.obs_buf[:]
+            else:
+                ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (rows * B, 1, B)).unbind(0))
+                ts.observations = ts.obs_buf.permute(2, 0, 1)
+            ts.traj_ptrs = _native.ptr_array([sb + j * leaf_e * isz for j in range(S)])
             ts.last = tuple(ts.lbuf[:, :B].unbind(0))
             ts.tens = (ts.observations,) + ts.st_views + ts.last
             ts.storages = [arena.untyped_storage(), ts.lbuf.untyped_storage()]
