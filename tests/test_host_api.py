@@ -500,11 +500,11 @@ def test_placement_search_memory_budget_for_the_c5_shard():
     b = CoreEnvironment.placement_memory_budget(B, rows, OW, S, isz, free_bytes=hbm - 8 * 10**9)
     assert abs(b["set"] - 25.53e9) < 0.05e9
     assert b["steady"] <= 52e9                       # two sets
-    assert b["search_peak"] <= 0.55 * hbm, b         # one live set + a search in progress: about half the device
+    assert b["search_peak"] <= 0.65 * hbm, b         # the live set, the set being replaced and a search in progress
     actions = B * 100 * 2 * isz
     gathered = 8 * B * OW * isz                      # the all-gathered final observation row of eight ranks
     assert b["steady"] + b["search_peak"] - b["set"] + actions + gathered < 0.75 * hbm
     assert b["searches_at_most"] == 4
     # a device that is already full leaves no room for spacers: the bound follows the free memory, not the constant
     tight = CoreEnvironment.placement_memory_budget(B, rows, OW, S, isz, free_bytes=30 * 10**9)
-    assert tight["search_peak"] < b["search_peak"] and tight["search_peak"] <= tight["set"] + 4 * 12e9 + 14e9 + 4 * 10e9 + 1e9
+    assert tight["search_peak"] < b["search_peak"] and tight["search_peak"] <= 2 * tight["set"] + 4 * 12e9 + 14e9 + 4 * 10e9 + 1e9
