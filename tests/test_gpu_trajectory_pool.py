@@ -54,7 +54,8 @@ def test_chained_run_alternates_between_two_sets_and_equals_the_unpooled_run(env
         del obs, states
     assert len(set(ptrs)) == 2 and ptrs[0] == ptrs[2] == ptrs[4] and ptrs[1] == ptrs[3] == ptrs[5]
     assert len(env._traj_sets) == 2
-    assert env.last_placement is not None and len(env.last_placement["candidate_ms"]) >= 1
+    lp = env.last_placement  # lane-major actions: judged by the access pattern against the fill rate (round 4), else by launch times
+    assert lp is not None and len(lp.get("candidate_pattern_over_fill") or lp.get("candidate_ms")) >= 1
 
 
 @pytest.mark.parametrize("held", ["observations", "state_leaf", "last_leaf", "view", "states_object", "detach"])
@@ -289,7 +290,7 @@ def test_arena_pair_is_made_once_reused_and_equals_the_unpooled_run():
     launches. The chained run alternates between them, holds the bits of the unpooled run, never writes a set somebody still
     sees, and a caller that holds on to outputs gets searched single sets from the third call on (no second arena)."""
     env, st = _env("pmsm", B=2048)
-    env._ARENA_MIN_SET_BYTES, env._ARENA_MIN_DISTANCE = 0, 0
+    env._ARENA_MIN_SET_BYTES, env._ARENA_MIN_DISTANCE, env._PATTERN_ACCEPT = 0, 0, 0.0  # test-sized sets: accept whatever the pattern says
     ref_env, ref_st = _env("pmsm", B=2048, pool=False)
     K = 12
     acts = [_actions(env, K, 80 + i) for i in range(5)]
@@ -310,7 +311,7 @@ def test_arena_pair_is_made_once_reused_and_equals_the_unpooled_run():
     assert ptrs[0] == ptrs[2] == ptrs[4] and ptrs[1] == ptrs[3] and ptrs[0] != ptrs[1]
     # a caller that keeps every output: the pair is used up after two calls, then single sets (no second arena)
     env2, st2 = _env("pmsm", B=2048)
-    env2._ARENA_MIN_SET_BYTES, env2._ARENA_MIN_DISTANCE = 0, 0
+    env2._ARENA_MIN_SET_BYTES, env2._ARENA_MIN_DISTANCE, env2._PATTERN_ACCEPT = 0, 0, 0.0
     held, s2 = [], st2
     for i in range(4):
         out = env2.vmap_sim_ahead(s2, acts[i], env2.tau, env2.tau)
@@ -323,3 +324,30 @@ def test_arena_pair_is_made_once_reused_and_equals_the_unpooled_run():
     for i in range(4):  # and what they hold is still what the unpooled run computes
         ro, _, s3 = ref_env.vmap_sim_ahead(s3 if i else ref_st, acts[i], ref_env.tau, ref_env.tau)
         assert torch.equal(held[i][0], ro)
+
+
+def test_pattern_judged_placement_accepts_on_the_absolute_criterion():
+    """The absolute placement criterion (pattern rate / fill rate >= _PATTERN_ACCEPT) with a scripted score: the search stops at
+    the first candidate that meets it, walks on while none does (keeping rejected blocks alive) and then keeps the best one."""
+    env, _ = _env("pmsm", B=1024)
+    env._PLACEMENT_SPACER_BYTES = 1 << 20
+    env._fill_gbs = 6800.0
+    B, rows, OW, S, isz = 1024, 12, 8, 7, 4
+
+    def run(scores):
+        it, seen = iter(scores), []
+
+        def fake(block):
+            seen.append(block.data_ptr())
+            return next(it)
+
+        obs_buf = torch.empty((rows, OW, B), dtype=torch.float32, device=env.device)
+        block, diag = env._place_state_block(obs_buf, B, rows, OW, S, isz, None, pattern=fake)
+        return block, diag, seen
+
+    block, diag, seen = run([(5.4, 0.76), (5.0, 0.83), (9.9, 0.9)])
+    assert diag["candidate_pattern_over_fill"] == [0.76, 0.83] and diag["chosen"] == 1 and block.data_ptr() == seen[1]
+    block, diag, seen = run([(5.0, 0.82)])
+    assert diag["candidate_pattern_over_fill"] == [0.82] and "candidate_ms" not in diag
+    block, diag, seen = run([(5.5, 0.70), (5.3, 0.74), (5.6, 0.69), (5.4, 0.72), (5.35, 0.73), (5.45, 0.71)])
+    assert len(diag["candidate_pattern_over_fill"]) == 6 and diag["chosen"] == 1 and len(set(seen)) == 6
