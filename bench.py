@@ -51,6 +51,17 @@ WORKLOADS = {
     "pmsm_sat_euler_f32": ("PMSM_SAT", "euler", torch.float32, 1e-4, 22, 100),  # saturated model, synthetic LUT
     "pmsm_sat_tsit5_f32": ("PMSM_SAT", "tsit5", torch.float32, 1e-4, 22, 100),
     "pmsm_sat_euler_f64": ("PMSM_SAT", "euler", torch.float64, 1e-4, 21, 100),
+    # more solver / dtype combinations of the small models (workgroup-shape sweep, tools/r4_block_sweep.sh)
+    "pendulum_euler_f64": ("PENDULUM", "euler", torch.float64, 2e-2, 21, 100),
+    "pendulum_tsit5_f32": ("PENDULUM", "tsit5", torch.float32, 2e-2, 22, 100),
+    "pendulum_rk4_f32": ("PENDULUM", "rk4", torch.float32, 2e-2, 22, 100),
+    "msd_tsit5_f32": ("MASS_SPRING_DAMPER", "tsit5", torch.float32, 1e-4, 22, 100),
+    "msd_euler_f64": ("MASS_SPRING_DAMPER", "euler", torch.float64, 1e-4, 21, 100),
+    "tank_tsit5_f32": ("FLUID_TANK", "tsit5", torch.float32, 1e-3, 22, 100),
+    "tank_euler_f64": ("FLUID_TANK", "euler", torch.float64, 1e-3, 21, 100),
+    "cartpole_tsit5_f32": ("CART_POLE", "tsit5", torch.float32, 2e-2, 22, 100),
+    "cartpole_euler_f64": ("CART_POLE", "euler", torch.float64, 2e-2, 21, 100),
+    "acrobot_euler_f64": ("ACROBOT", "euler", torch.float64, 1e-3, 21, 100),
 }
 ORACLE_NAME = {"PMSM": "pmsm", "PENDULUM": "pendulum", "MASS_SPRING_DAMPER": "mass_spring_damper", "CART_POLE": "cartpole",
                "ACROBOT": "acrobot", "FLUID_TANK": "fluid_tank"}

@@ -16,6 +16,13 @@ namespace excenv {
 #define EXCENV_PINGPONG 1  // bit 0: Euler, bit 1: RK4 / Tsit5 — K loop unrolled by two with ping-pong action registers
 #endif                      // (2-step prefetch distance, 2x loop code). Measured: +3.5 % Euler, -5 % Tsit5.
 constexpr int BLOCK = EXCENV_BLOCK;
+// Experiment switch (profiles/r04_pattern_sweep.md): a workgroup barrier before the stores of every row. The no-arithmetic access
+// pattern gains 3 % (256 threads) ... 6.6 % (1024 threads) from waves that store a stream's run together; the real kernel LOSES
+// 4.5 % (256 threads) / 2 % (512 threads, barrier) / 5 % (512 threads, no barrier) in a same-buffers A/B (tools/ab_same_buffers.py):
+// lockstep takes away the overlap of one wave's arithmetic with another's stores.
+#ifndef EXCENV_ROW_BARRIER
+#define EXCENV_ROW_BARRIER 0
+#endif
 
 // Property leaves in kernel-argument order: P statics, S mins, S maxs, A mins, A maxs.
 template <typename T, class M> struct KProps {
@@ -423,9 +430,20 @@ template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return 
 // depends on the references alone is computed once per trajectory, per row one sin / cos per controlled ANGLE and environment, and
 // O + n_control packed flag stores. The general instantiation (one environment per lane, byte stores, the reward loop unrolled over
 // eight possible controls) took 7.5 ms (PMSM) / 4.5 ms (pendulum) for launches the lean kernels do in 4.9 / 1.6.
-template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false, bool LGYM = false>
-__global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka) {
+//
+// NT (round 4): threads per workgroup. The Euler kernels of the two- and one-leaf models (pendulum, mass-spring-damper, tank) do so
+// little arithmetic per row that their waves mostly wait for memory; sixteen waves that store a row TOGETHER (one barrier per row)
+// write 16 KiB runs per stream where four unsynchronised waves wrote 1 KiB runs whenever each got there, and the memory side
+// rewards that: pendulum Euler fp32 (C2) 3.98 -> 3.56 ms, MSD Euler 1.53 -> 1.43, tank 0.87 -> 0.81 in a same-buffers A/B
+// (tools/ab_same_buffers.py, profiles/r04_pattern_sweep.md). With more arithmetic per row (RK4 / Tsit5, cart-pole, acrobot, PMSM)
+// lockstep takes away the overlap of one wave's arithmetic with another's stores and the same change LOSES 2 ... 9 %: NT == BLOCK
+// there, no barrier. sim_threads<M, T>() (launch.hpp) is the rule.
+template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false, bool LGYM = false,
+          int NT = BLOCK>
+__global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
+  static_assert(NT == BLOCK || (!GENERAL && !AEM && !LGYM && !M::HAS_LUT), "wide workgroups: plain lean instantiations only");
+  constexpr bool ROW_BARRIER = (NT > BLOCK) || (EXCENV_ROW_BARRIER != 0);
   // GENERAL stays at one environment per lane. Round 4 tried two, each with its own property set (a second Ctx in registers:
   // every leaf may differ per environment, so none can stay in SGPRs — 195 registers, two waves per SIMD): 5.91 ... 6.27 ms for one,
   // 6.02 ... 6.06 for two (tools/general_path_cost.py, two sessions) — no gain, removed. What did help is compiling the gym
@@ -437,7 +455,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
   constexpr bool GYM = GENERAL && STATES == -1;
   static_assert(!AEM || (!GENERAL && !M::HAS_LUT && aem_shape_ok<T, V>() && (16 / (int)sizeof(T)) % A == 0),
                 "row-major actions are fused into the widest lean instantiation only");
-  const int64_t blk0 = (int64_t)blockIdx.x * (BLOCK * V);  // first env of this workgroup
+  const int64_t blk0 = (int64_t)blockIdx.x * (NT * V);  // first env of this workgroup
   const unsigned lane_env = threadIdx.x * V;
   const int64_t i0 = blk0 + lane_env;
   Ctx<T, M> cs[NC];
@@ -600,6 +618,7 @@ __global__ void __launch_bounds__(BLOCK) sim_ahead_kernel(const SimArgs<T, M> ka
 #pragma unroll
     for (int v = 0; v < V; ++v) M::observe(sv[v], EXCENV_CX(v), ob[v]);
     T* orow = o_blk + n * ka.o_sk;
+    if constexpr (ROW_BARRIER && V > 1) __builtin_amdgcn_s_barrier();  // the waves of a workgroup store a row together
 #pragma unroll
     for (int q = 0; q < O; ++q) {
       T tmp[V];

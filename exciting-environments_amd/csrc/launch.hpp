@@ -358,13 +358,33 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
   return check_launch("excenv_step");
 }
 
+// Threads per workgroup of the plain lean trajectory kernel (kernels.hpp, NT): 1024 with one barrier per row for the Euler kernels of
+// the small models, BLOCK everywhere else — measured per workload (profiles/r04_pattern_sweep.md): pendulum Euler fp32 -10.6 %, fp64
+// -8 %, MSD Euler fp32 -7 %, fp64 -6 %, tank Euler fp32 -6 % (fp64 +3 %: not taken); RK4 / Tsit5 of the same models +3 ... +9 %,
+// cart-pole / acrobot Euler within 3 % either way, PMSM (256 registers) not possible.
+constexpr int WIDE_THREADS = 1024;
+constexpr int64_t WIDE_MIN_WORKGROUPS = 256;  // at least one wide workgroup per CU of the MI355X, else the narrow form fills the chip better
+template <class M, typename T> constexpr bool sim_wide_ok(int solver) {
+  return solver == EXCENV_EULER && !M::HAS_LUT &&
+         (M::ID == EXCENV_PENDULUM || M::ID == EXCENV_MASS_SPRING_DAMPER || (M::ID == EXCENV_FLUID_TANK && sizeof(T) == 4));
+}
+
 template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(const SimCall& sc_in, const SimArgs<T, M>& ka_in,
-                                                                                 bool general, int V, bool aem = false, bool lgym = false) {
+                                                                                 bool general, int V, bool aem = false, bool lgym = false,
+                                                                                 int nt = BLOCK) {
   SimArgs<T, M> ka = ka_in;
   SimCall sc = sc_in;
   sc.lds_pad = (int)lut_lds_bytes<T, M>(ka.kp, (size_t)sc_in.lds_pad);
   const int64_t lanes = sc.B / V;
-  const dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK)), block(BLOCK);
+  const dim3 grid((unsigned)((lanes + nt - 1) / nt)), block(nt);
+  if constexpr (sim_wide_ok<M, T>(SOLVER)) {
+    if (nt == WIDE_THREADS) {  // the widest lean form in 1024-thread workgroups, one barrier per row (launch_sim decides)
+      constexpr int VA = 16 / (int)sizeof(T);
+      if (ka.straj[0] == nullptr) EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 0, false, false, false, WIDE_THREADS>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
+      else EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 1, false, false, false, WIDE_THREADS>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
+      return;
+    }
+  }
   if constexpr (!M::HAS_LUT) {
     if (lgym) {  // the gym trajectories out of the widest lean form (V == 16 / sizeof(T))
       constexpr int VA = 16 / (int)sizeof(T);
@@ -616,8 +636,12 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
       V = VT;
     }
   }
+  int nt = BLOCK;
+  if (sim_wide_ok<M, T>(sc.solver) && !general && !aem && !lean_gym && !tiled_a && !tiled_t && V == VMAX &&
+      sc.B / V >= WIDE_THREADS * WIDE_MIN_WORKGROUPS)
+    nt = WIDE_THREADS;
   {  // element offset of workgroup w's first env in each stream
-    const int64_t wg_envs = (int64_t)BLOCK * V;
+    const int64_t wg_envs = (int64_t)nt * V;
     auto wg_off = [&](int layout, int64_t sb, int64_t per_tile) -> int64_t {
       if (layout == EXCENV_LAYOUT_TILED) return (wg_envs == TILE) ? per_tile : -1;
       return wg_envs * sb;
@@ -632,8 +656,8 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   }
 #define EXCENV_SIM_CASE(SOLV)                                                         \
   case SOLV:                                                                          \
-    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(sc, ka, general, V, aem && V == VMAX, lean_gym);  \
-    else launch_sim_v<M, T, SOLV, false>(sc, ka, general, V, aem && V == VMAX, lean_gym);                         \
+    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(sc, ka, general, V, aem && V == VMAX, lean_gym, nt);  \
+    else launch_sim_v<M, T, SOLV, false>(sc, ka, general, V, aem && V == VMAX, lean_gym, nt);                         \
     break;
   switch (sc.solver) {
     EXCENV_SIM_CASE(EXCENV_EULER)
@@ -642,7 +666,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
   }
 #undef EXCENV_SIM_CASE
-  g_last_launch = general ? "sim_ahead_kernel (general)" : (lean_gym ? "sim_ahead_kernel (lean, gym outputs)" : aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? "sim_ahead_kernel (V=2)" : "sim_ahead_kernel (V=4)")));
+  g_last_launch = general ? "sim_ahead_kernel (general)" : (lean_gym ? "sim_ahead_kernel (lean, gym outputs)" : aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? (nt > BLOCK ? "sim_ahead_kernel (V=2, 1024 threads)" : "sim_ahead_kernel (V=2)") : (nt > BLOCK ? "sim_ahead_kernel (V=4, 1024 threads)" : "sim_ahead_kernel (V=4)"))));
   if (int rc = check_launch("excenv_sim_ahead")) return rc;
   if (split_control && !general) {
     ControlFillArgs<T, M> fa;

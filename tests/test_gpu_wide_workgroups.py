@@ -1,0 +1,100 @@
+"""The 1024-thread form of the plain lean trajectory kernel (csrc/kernels.hpp NT, csrc/launch.hpp sim_wide_ok): the Euler kernels of
+pendulum, mass-spring-damper and (fp32) fluid tank run in 1024-thread workgroups with one barrier per row once the batch gives every
+CU such a workgroup. Same arithmetic as every other form: the results must be the BITS of the 256-thread form (forced here by asking
+for two environments per lane) and match the oracle directly; a ragged batch (waves that leave before the first barrier, a partly
+filled last wave), both semantics, observations only, sub-steps. ``-m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from exciting_environments_amd import _native
+from helpers import ANGLE_STATES, NP_DTYPE, circ_close, make_env, max_err, random_state, to_state
+
+pytestmark = pytest.mark.gpu
+
+WIDE = [("pendulum", torch.float32), ("pendulum", torch.float64), ("mass_spring_damper", torch.float32),
+        ("mass_spring_damper", torch.float64), ("fluid_tank", torch.float32)]
+
+
+def _b_min(dtype):
+    return (1 << 20) if dtype is torch.float32 else (1 << 19)  # 256 workgroups of 1024 threads x 16 / sizeof(T) environments
+
+
+def _run(env, st, acts, sub=1):
+    out = env.vmap_sim_ahead(to_state(env, st), acts, env.tau / sub, env.tau)
+    torch.cuda.synchronize()
+    return out, _native.last_launch()
+
+
+@pytest.mark.parametrize("env_name,dtype", WIDE)
+@pytest.mark.parametrize("semantics", ["ahead", "step"])
+@pytest.mark.parametrize("extra", [0, 1000])  # whole workgroups / a ragged tail (1000 environments: 3 whole waves + a partly filled one)
+def test_wide_workgroups_have_the_bits_of_the_narrow_form_and_match_the_oracle(env_name, dtype, semantics, extra):
+    B, K = _b_min(dtype) + extra, 24
+    env, props, keep, spec = make_env(env_name, B, dtype)
+    env.sim_ahead_semantics = semantics
+    env.trajectory_pool = False
+    st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=71)
+    acts_np = np.random.default_rng(72).uniform(-1, 1, (B, K, env.action_dim)).astype(NP_DTYPE[dtype])
+    acts = env.new_actions_buffer(K)
+    acts.copy_(torch.as_tensor(acts_np, device=env.device))
+    (obs, states, last), name = _run(env, st, acts)
+    assert "1024 threads" in name, name
+    env.launch_opts = _native.launch_opts(envs_per_lane=(2 if dtype is torch.float32 else 1))
+    (obs2, states2, last2), name2 = _run(env, st, acts)
+    assert "1024" not in name2, name2
+    assert torch.equal(obs, obs2)
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(states.physical_state, n), getattr(states2.physical_state, n)), n
+        assert torch.equal(getattr(last.physical_state, n), getattr(last2.physical_state, n)), n
+    # the oracle on the first workgroup, on one in the middle and on the tail
+    sem = oracle.SEM_STEP if semantics == "step" else oracle.SEM_AHEAD
+    n = 1200
+    for sl in (slice(0, n), slice(B // 2 - 7, B // 2 - 7 + n), slice(B - n, B)):
+        sub_props, _k = oracle.make_props(env_name, spec["params"], spec["phys_norm"], spec["act_norm"], NP_DTYPE[dtype], n)
+        o_ref, s_ref, l_ref = oracle.sim_ahead(env_name, "euler", [s[sl] for s in st], acts_np[sl], sub_props, spec["tau"], semantics=sem)
+        rtol, atol = (1e-5, 2e-5) if dtype is torch.float32 else (1e-10, 1e-10)
+        got = obs[sl].cpu().numpy()
+        assert circ_close(got, o_ref, {"pendulum": [0]}.get(env_name, []), rtol, atol), max_err(got, o_ref)
+        for j, name_j in enumerate(env.STATE_FIELDS):
+            g = getattr(states.physical_state, name_j)[sl].cpu().numpy()
+            scale = max(1.0, float(np.nanmax(np.abs(s_ref[j]))))
+            if j in ANGLE_STATES.get(env_name, []):
+                assert circ_close(g[..., None], s_ref[j][..., None], [0], rtol, atol * scale, period=2 * np.pi), name_j
+            else:
+                assert np.allclose(g, s_ref[j], rtol=rtol, atol=atol * scale), (name_j, max_err(g, s_ref[j]))
+
+
+@pytest.mark.parametrize("env_name,dtype", [("pendulum", torch.float32), ("mass_spring_damper", torch.float64)])
+def test_wide_workgroups_observations_only_and_substeps(env_name, dtype):
+    B, K, sub = _b_min(dtype), 10, 3
+    env, props, keep, spec = make_env(env_name, B, dtype)
+    env.trajectory_pool = False
+    env.store_state_trajectory = False
+    st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=73)
+    acts = env.new_actions_buffer(K)
+    acts.copy_(torch.as_tensor(np.random.default_rng(74).uniform(-1, 1, (B, K, 1)).astype(NP_DTYPE[dtype]), device=env.device))
+    (obs, states, last), name = _run(env, st, acts, sub)
+    assert "1024 threads" in name and states is None and tuple(obs.shape)[:2] == (B, K * sub + 1)
+    env.launch_opts = _native.launch_opts(envs_per_lane=(2 if dtype is torch.float32 else 1))
+    (obs2, _s, last2), name2 = _run(env, st, acts, sub)
+    assert "1024" not in name2 and torch.equal(obs, obs2)
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(last.physical_state, n), getattr(last2.physical_state, n)), n
+
+
+@pytest.mark.parametrize("env_name,dtype,solver,B", [
+    ("pendulum", torch.float32, "tsit5", 1 << 20),   # more arithmetic per row: narrow workgroups stay (measured slower wide)
+    ("fluid_tank", torch.float64, "euler", 1 << 19),
+    ("cartpole", torch.float32, "euler", 1 << 20),
+    ("pendulum", torch.float32, "euler", 1 << 19),   # fewer than one wide workgroup per CU
+])
+def test_narrow_workgroups_stay_where_the_wide_form_measured_no_gain(env_name, dtype, solver, B):
+    env, props, keep, spec = make_env(env_name, B, dtype, solver=solver)
+    env.trajectory_pool = False
+    st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=75)
+    acts = env.new_actions_buffer(4)
+    acts.zero_()
+    _out, name = _run(env, st, acts)
+    assert "1024" not in name, name

@@ -12,7 +12,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "exciting-environments_amd", "csrc")
-KERNEL = "_ZN6excenv16sim_ahead_kernelINS_4PmsmIfEEfLi0ELb1ELb0ELi4ELi1ELb0ELb0ELb0EEEvNS_7SimArgsIT0_T_EE"
+KERNEL = "_ZN6excenv16sim_ahead_kernelINS_4PmsmIfEEfLi0ELb1ELb0ELi4ELi1ELb0ELb0ELb0ELi256EEEvNS_7SimArgsIT0_T_EE"
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_sim_ahead_loop_isa.md")
 flags = "-O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function".split()
 with tempfile.TemporaryDirectory() as td:

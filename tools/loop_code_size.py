@@ -18,7 +18,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "exciting-environments_amd", "exciting_environments_amd", "lib", "libexcenv_hip.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-HEADLINE = "_ZN6excenv16sim_ahead_kernelINS_4PmsmIfEEfLi0ELb1ELb0ELi4ELi1ELb0ELb0ELb0EEEvNS_7SimArgsIT0_T_EE"
+HEADLINE = "_ZN6excenv16sim_ahead_kernelINS_4PmsmIfEEfLi0ELb1ELb0ELi4ELi1ELb0ELb0ELb0ELi256EEEvNS_7SimArgsIT0_T_EE"
 
 
 def loop_spans(lib=LIB):
