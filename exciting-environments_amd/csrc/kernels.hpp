@@ -60,6 +60,7 @@ template <typename T, class M> struct SimArgs {
   int64_t B, K;
   int32_t substeps;
   int32_t n_control;
+  int32_t row_sync;  // one-environment-per-lane instantiations: 1 = a workgroup barrier before the stores of every row, 2 = rows leave through LDS as 16-byte stores (launch.hpp)
   const T* state_in[M::S];
   T* last_state[M::S];
   const T* actions;
@@ -442,6 +443,7 @@ template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int 
           int NT = BLOCK>
 __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
+  extern __shared__ __align__(16) unsigned char excenv_smem[];
   static_assert(NT == BLOCK || (!GENERAL && !AEM && !LGYM && !M::HAS_LUT), "wide workgroups: plain lean instantiations only");
   constexpr bool ROW_BARRIER = (NT > BLOCK) || (EXCENV_ROW_BARRIER != 0);
   // GENERAL stays at one environment per lane. Round 4 tried two, each with its own property set (a second Ctx in registers:
@@ -618,32 +620,78 @@ __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
 #pragma unroll
     for (int v = 0; v < V; ++v) M::observe(sv[v], EXCENV_CX(v), ob[v]);
     T* orow = o_blk + n * ka.o_sk;
-    if constexpr (ROW_BARRIER && V > 1) __builtin_amdgcn_s_barrier();  // the waves of a workgroup store a row together
+    // the waves of a workgroup store a row together: always in the wide-workgroup form; with one environment per lane (4-byte
+    // stores, 256-byte runs per wave and stream) where the host asks for it — PMSM with per-environment properties at B = 2^22:
+    // 6.29 -> 5.50 ms (0.567 -> 0.648 of the roof), the lean V = 1 form 6.34 -> 5.61
+    bool direct = true;
+    if constexpr (ROW_BARRIER) {
+      __builtin_amdgcn_s_barrier();
+    } else if constexpr (V == 1 && !M::HAS_LUT && !AEM) {
+      // row_sync == 2 (lane-major arrays, whole workgroups, 16-byte aligned): the row goes through LDS — every lane leaves its
+      // values as [stream][lane] words, one barrier, then the waves share the streams and store 16 bytes per lane: 1 KiB runs per
+      // instruction instead of 256-byte ones, a quarter of the store instructions. Two buffers alternate, so the barrier of row
+      // n + 1 is also the one that frees row n's buffer.
+      if (ka.row_sync == 2) {
+        constexpr int VE = 16 / (int)sizeof(T), CH = NT / (64 * VE), NW = NT / 64;
+        const int OWr = O + (GENERAL ? ka.n_control : 0);
+        const int NS = OWr + (with_states ? S : 0);
+        T* buf = reinterpret_cast<T*>(excenv_smem) + (unsigned)(n & 1) * (unsigned)(NS * NT);
 #pragma unroll
-    for (int q = 0; q < O; ++q) {
-      T tmp[V];
+        for (int q = 0; q < O; ++q) buf[q * NT + threadIdx.x] = ob[0][q];
+        if constexpr (GENERAL) {
 #pragma unroll
-      for (int v = 0; v < V; ++v) tmp[v] = ob[v][q];
-      store_stream<T, V>(orow + q * ka.o_sc + o_lane, tmp);
-    }
-    if constexpr (GENERAL) {
-#pragma unroll
-      for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
-        if (j < ka.n_control) {
-          T tmp[V];
-#pragma unroll
-          for (int v = 0; v < V; ++v) tmp[v] = cref[v][j];
-          store_v<T, V>(orow + (O + j) * ka.o_sc + o_lane, tmp);
+          for (int j = 0; j < EXCENV_MAX_CONTROL; ++j)
+            if (j < ka.n_control) buf[(O + j) * NT + threadIdx.x] = cref[0][j];
         }
-      }
-    }
-    if (with_states) {
+        if (with_states) {
 #pragma unroll
-      for (int j = 0; j < S; ++j) {
+          for (int j = 0; j < S; ++j) buf[(OWr + j) * NT + threadIdx.x] = sv[0][j];
+        }
+        __builtin_amdgcn_s_barrier();  // (LDS writes above are waited for by the compiler's s_waitcnt before the barrier)
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const unsigned ln = threadIdx.x & 63u;
+        for (int u = wv; u < NS * CH; u += NW) {
+          const int q = u / CH;
+          const unsigned e = (unsigned)(u % CH) * (64u * VE) + ln * VE;
+          T tmp[VE];
+          load_v<T, VE>(buf + q * NT + e, tmp);
+          T* dst = (q < OWr) ? orow + q * ka.o_sc : ka.straj[q - OWr] + s_blk + n * ka.s_sk;
+          store_stream<T, VE>(dst + e, tmp);
+        }
+        direct = false;
+      } else if (ka.row_sync) {
+        __builtin_amdgcn_s_barrier();
+      }
+    } else if constexpr (V == 1) {
+      if (ka.row_sync) __builtin_amdgcn_s_barrier();
+    }
+    if (direct) {
+#pragma unroll
+      for (int q = 0; q < O; ++q) {
         T tmp[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) tmp[v] = sv[v][j];
-        store_stream<T, V>(ka.straj[j] + s_blk + n * ka.s_sk + s_lane, tmp);
+        for (int v = 0; v < V; ++v) tmp[v] = ob[v][q];
+        store_stream<T, V>(orow + q * ka.o_sc + o_lane, tmp);
+      }
+      if constexpr (GENERAL) {
+#pragma unroll
+        for (int j = 0; j < EXCENV_MAX_CONTROL; ++j) {
+          if (j < ka.n_control) {
+            T tmp[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) tmp[v] = cref[v][j];
+            store_v<T, V>(orow + (O + j) * ka.o_sc + o_lane, tmp);
+          }
+        }
+      }
+      if (with_states) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          T tmp[V];
+#pragma unroll
+          for (int v = 0; v < V; ++v) tmp[v] = sv[v][j];
+          store_stream<T, V>(ka.straj[j] + s_blk + n * ka.s_sk + s_lane, tmp);
+        }
       }
     }
     if constexpr (LGYM && !M::IS_PMSM) {  // generate_reward / generate_truncated / generate_terminated of the other models, V wide
@@ -757,7 +805,6 @@ __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int RW = NP * SP;              // rows per window
   constexpr int EPI = 64 / NP;             // environments (reader lanes) per load instruction
   static_assert(64 % NP == 0, "a load instruction covers whole windows");
-  extern __shared__ __align__(16) unsigned char excenv_smem[];
   const unsigned wave = threadIdx.x / 64u, lane64 = threadIdx.x % 64u;
   const unsigned wave_off = AEM ? __builtin_amdgcn_readfirstlane(wave * (unsigned)(V * NP * AEM_BLOCK_BYTES)) : 0u;  // this wave's blocks
   const unsigned wave_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)excenv_smem + wave_off;  // as an LDS address

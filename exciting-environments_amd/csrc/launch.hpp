@@ -362,6 +362,15 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
 // the small models, BLOCK everywhere else — measured per workload (profiles/r04_pattern_sweep.md): pendulum Euler fp32 -10.6 %, fp64
 // -8 %, MSD Euler fp32 -7 %, fp64 -6 %, tank Euler fp32 -6 % (fp64 +3 %: not taken); RK4 / Tsit5 of the same models +3 ... +9 %,
 // cart-pole / acrobot Euler within 3 % either way, PMSM (256 registers) not possible.
+#ifndef EXCENV_ROW_SYNC_MIN_BATCH
+#define EXCENV_ROW_SYNC_MIN_BATCH ((int64_t)1 << 17)
+#endif
+constexpr int64_t ROW_SYNC_MIN_BATCH = EXCENV_ROW_SYNC_MIN_BATCH;
+static inline int row_sync_mode() {  // EXCENV_ROW_SYNC = 0: off, 1: barrier only, default 2: rows through LDS where possible
+  static const int mode = [] { const char* e = std::getenv("EXCENV_ROW_SYNC"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
+  return mode;
+}
+static inline bool row_sync_enabled() { return row_sync_mode() != 0; }
 constexpr int WIDE_THREADS = 1024;
 constexpr int64_t WIDE_MIN_WORKGROUPS = 256;  // at least one wide workgroup per CU of the MI355X, else the narrow form fills the chip better
 template <class M, typename T> constexpr bool sim_wide_ok(int solver) {
@@ -469,6 +478,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     for (int j = 0; j < ka.n_control; ++j) split_control &= sc.control->reference[j] != nullptr;
   }
   bool general = batched || (ka.n_control > 0 && !split_control) || (with_gym && !lean_gym);
+  bool traj_aligned = aligned16(sc.obs_traj);  // the trajectory arrays alone (row_sync == 2 below)
   bool vec_ok = true;  // every pointer 16-byte aligned (checked below); the general instantiation goes up to two environments per lane
   for (int j = 0; j < M::S; ++j) {
     if (!sc.state_in[j] || !sc.last_state[j]) { set_error("excenv_sim_ahead: state pointer %d is NULL", j); return EXCENV_ENULL; }
@@ -477,6 +487,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     ka.straj[j] = sc.state_traj ? (T*)sc.state_traj[j] : nullptr;
     if (sc.state_traj && !sc.state_traj[j]) { set_error("excenv_sim_ahead: state_traj pointer %d is NULL", j); return EXCENV_ENULL; }
     vec_ok &= aligned16(ka.state_in[j]) && aligned16(ka.last_state[j]) && aligned16(ka.straj[j]);
+    traj_aligned &= aligned16(ka.straj[j]);
   }
   ka.actions = (const T*)sc.actions;
   ka.obs = (T*)sc.obs_traj;
@@ -636,6 +647,16 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
       V = VT;
     }
   }
+  // one environment per lane at a batch that fills the chip several times over: the four waves of a workgroup store each row
+  // together (kernels.hpp row_sync). EXCENV_ROW_SYNC=0 switches it off (A/B measurements).
+  ka.row_sync = (V == 1 && sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR && sc.B >= ROW_SYNC_MIN_BATCH && row_sync_enabled()) ? 1 : 0;
+  size_t row_lds = 0;
+  if (ka.row_sync && !M::HAS_LUT && !aem && (sc.B % BLOCK) == 0 && traj_aligned && row_sync_mode() >= 2) {
+    // whole workgroups and aligned arrays: the rows leave through LDS as 16-byte stores (kernels.hpp, row_sync == 2)
+    const size_t ns = (size_t)OW + (ka.straj[0] ? M::S : 0);
+    const size_t bytes = 2 * ns * BLOCK * sizeof(T);
+    if (bytes <= ((size_t)64 << 10)) { ka.row_sync = 2; row_lds = bytes; }
+  }
   int nt = BLOCK;
   if (sim_wide_ok<M, T>(sc.solver) && !general && !aem && !lean_gym && !tiled_a && !tiled_t && V == VMAX &&
       sc.B / V >= WIDE_THREADS * WIDE_MIN_WORKGROUPS)
@@ -654,10 +675,12 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
       return EXCENV_EUNSUPPORTED;
     }
   }
+  SimCall scl = sc;
+  scl.lds_pad += (int)row_lds;
 #define EXCENV_SIM_CASE(SOLV)                                                         \
   case SOLV:                                                                          \
-    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(sc, ka, general, V, aem && V == VMAX, lean_gym, nt);  \
-    else launch_sim_v<M, T, SOLV, false>(sc, ka, general, V, aem && V == VMAX, lean_gym, nt);                         \
+    if (sc.semantics == EXCENV_SEM_AHEAD) launch_sim_v<M, T, SOLV, true>(scl, ka, general, V, aem && V == VMAX, lean_gym, nt);  \
+    else launch_sim_v<M, T, SOLV, false>(scl, ka, general, V, aem && V == VMAX, lean_gym, nt);                         \
     break;
   switch (sc.solver) {
     EXCENV_SIM_CASE(EXCENV_EULER)
