@@ -444,7 +444,7 @@ template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int 
 __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
   extern __shared__ __align__(16) unsigned char excenv_smem[];
-  static_assert(NT == BLOCK || (!GENERAL && !AEM && !LGYM && !M::HAS_LUT), "wide workgroups: plain lean instantiations only");
+  static_assert(NT == BLOCK || (!GENERAL && !AEM && !M::HAS_LUT), "wide workgroups: lean instantiations only (plain or with gym outputs)");
   constexpr bool ROW_BARRIER = (NT > BLOCK) || (EXCENV_ROW_BARRIER != 0);
   // GENERAL stays at one environment per lane. Round 4 tried two, each with its own property set (a second Ctx in registers:
   // every leaf may differ per environment, so none can stay in SGPRs — 195 registers, two waves per SIMD): 5.91 ... 6.27 ms for one,

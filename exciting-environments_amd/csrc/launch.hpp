@@ -378,6 +378,9 @@ template <class M, typename T> constexpr bool sim_wide_ok(int solver) {
          (M::ID == EXCENV_PENDULUM || M::ID == EXCENV_MASS_SPRING_DAMPER || (M::ID == EXCENV_FLUID_TANK && sizeof(T) == 4));
 }
 
+// with the gym outputs' code the pendulum instantiations need 128 ... 145 registers: they would spill under the 1024-thread bound
+template <class M, typename T> constexpr bool sim_wide_gym_ok(int solver) { return sim_wide_ok<M, T>(solver) && M::ID != EXCENV_PENDULUM; }
+
 template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(const SimCall& sc_in, const SimArgs<T, M>& ka_in,
                                                                                  bool general, int V, bool aem = false, bool lgym = false,
                                                                                  int nt = BLOCK) {
@@ -387,7 +390,7 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + nt - 1) / nt)), block(nt);
   if constexpr (sim_wide_ok<M, T>(SOLVER)) {
-    if (nt == WIDE_THREADS) {  // the widest lean form in 1024-thread workgroups, one barrier per row (launch_sim decides)
+    if (nt == WIDE_THREADS && !lgym) {  // the widest lean form in 1024-thread workgroups, one barrier per row (launch_sim decides)
       constexpr int VA = 16 / (int)sizeof(T);
       if (ka.straj[0] == nullptr) EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 0, false, false, false, WIDE_THREADS>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
       else EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 1, false, false, false, WIDE_THREADS>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
@@ -397,6 +400,13 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
   if constexpr (!M::HAS_LUT) {
     if (lgym) {  // the gym trajectories out of the widest lean form (V == 16 / sizeof(T))
       constexpr int VA = 16 / (int)sizeof(T);
+      if constexpr (sim_wide_gym_ok<M, T>(SOLVER)) {
+        if (nt == WIDE_THREADS) {
+          if (ka.straj[0] == nullptr) EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 0, false, false, true, WIDE_THREADS>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
+          else EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 1, false, false, true, WIDE_THREADS>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
+          return;
+        }
+      }
       if (ka.straj[0] == nullptr) EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 0, false, false, true>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
       else EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 1, false, false, true>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
       return;
@@ -649,7 +659,9 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   }
   // one environment per lane at a batch that fills the chip several times over: the four waves of a workgroup store each row
   // together (kernels.hpp row_sync). EXCENV_ROW_SYNC=0 switches it off (A/B measurements).
-  ka.row_sync = (V == 1 && sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR && sc.B >= ROW_SYNC_MIN_BATCH && row_sync_enabled()) ? 1 : 0;
+  // (not with the gym outputs' code in the loop: with that much arithmetic per row lockstep costs more than the stores gain —
+  // PMSM 7.06 -> 8.59 ms, pendulum 4.64 -> 5.28, acrobot 7.0 -> 8.0 measured)
+  ka.row_sync = (V == 1 && !with_gym && sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR && sc.B >= ROW_SYNC_MIN_BATCH && row_sync_enabled()) ? 1 : 0;
   size_t row_lds = 0;
   if (ka.row_sync && !M::HAS_LUT && !aem && (sc.B % BLOCK) == 0 && traj_aligned && row_sync_mode() >= 2) {
     // whole workgroups and aligned arrays: the rows leave through LDS as 16-byte stores (kernels.hpp, row_sync == 2)
@@ -658,7 +670,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     if (bytes <= ((size_t)64 << 10)) { ka.row_sync = 2; row_lds = bytes; }
   }
   int nt = BLOCK;
-  if (sim_wide_ok<M, T>(sc.solver) && !general && !aem && !lean_gym && !tiled_a && !tiled_t && V == VMAX &&
+  if (sim_wide_ok<M, T>(sc.solver) && (!lean_gym || sim_wide_gym_ok<M, T>(sc.solver)) && !general && !aem && !tiled_a && !tiled_t && V == VMAX &&
       sc.B / V >= WIDE_THREADS * WIDE_MIN_WORKGROUPS)
     nt = WIDE_THREADS;
   {  // element offset of workgroup w's first env in each stream
@@ -689,7 +701,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
   }
 #undef EXCENV_SIM_CASE
-  g_last_launch = general ? "sim_ahead_kernel (general)" : (lean_gym ? "sim_ahead_kernel (lean, gym outputs)" : aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? (nt > BLOCK ? "sim_ahead_kernel (V=2, 1024 threads)" : "sim_ahead_kernel (V=2)") : (nt > BLOCK ? "sim_ahead_kernel (V=4, 1024 threads)" : "sim_ahead_kernel (V=4)"))));
+  g_last_launch = general ? "sim_ahead_kernel (general)" : (lean_gym ? (nt > BLOCK ? "sim_ahead_kernel (lean, gym outputs, 1024 threads)" : "sim_ahead_kernel (lean, gym outputs)") : aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? (nt > BLOCK ? "sim_ahead_kernel (V=2, 1024 threads)" : "sim_ahead_kernel (V=2)") : (nt > BLOCK ? "sim_ahead_kernel (V=4, 1024 threads)" : "sim_ahead_kernel (V=4)"))));
   if (int rc = check_launch("excenv_sim_ahead")) return rc;
   if (split_control && !general) {
     ControlFillArgs<T, M> fa;

@@ -98,3 +98,48 @@ def test_narrow_workgroups_stay_where_the_wide_form_measured_no_gain(env_name, d
     acts.zero_()
     _out, name = _run(env, st, acts)
     assert "1024" not in name, name
+
+
+@pytest.mark.parametrize("env_name,control", [("mass_spring_damper", ["deflection"]), ("fluid_tank", ["height"]), ("fluid_tank", [])])
+@pytest.mark.parametrize("semantics", ["ahead", "step"])
+def test_gym_trajectories_from_wide_workgroups_equal_the_general_kernel(env_name, control, semantics):
+    """reward / terminated / truncated trajectories (core_env.py:490-531) out of the 1024-thread lean kernel (mass-spring-damper and
+    tank; the pendulum's instantiation with the gym code would spill under the 1024-thread register bound and stays narrow): the
+    bits of the one-environment-per-lane general kernel."""
+    B, K = 1 << 20, 9
+    env, props, keep, spec = make_env(env_name, B, torch.float32, control_state=list(control))
+    env.sim_ahead_semantics = semantics
+    env.trajectory_pool = False
+    st = random_state(env_name, B, np.float32, spec, seed=76)
+    st[0] = (st[0] * 1.3).astype(np.float32)  # some states outside the normalisation box: truncated flags of both kinds
+    rng = np.random.default_rng(77)
+    refs = {}
+    for n in control:
+        lo, hi = spec["phys_norm"][n]
+        refs[n] = rng.uniform(1.2 * lo if lo < 0 else lo, 1.2 * hi, B).astype(np.float32)
+    acts = env.new_actions_buffer(K)
+    acts.copy_(torch.as_tensor(rng.uniform(-1, 1, (B, K, 1)).astype(np.float32), device=env.device))
+    outs = {}
+    for vec in (4, 1):
+        env.launch_opts = _native.launch_opts(envs_per_lane=vec) if vec == 1 else None
+        outs[vec] = env.vmap_sim_ahead(to_state(env, st, reference=refs), acts, env.tau, env.tau, return_rew_trunc_term=True)
+        torch.cuda.synchronize()
+        assert _native.last_launch() == ("sim_ahead_kernel (lean, gym outputs, 1024 threads)" if vec == 4 else "sim_ahead_kernel (general)")
+    a, b = outs[4], outs[1]
+    assert torch.equal(a[0], b[0])
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(a[1].physical_state, n), getattr(b[1].physical_state, n)), n
+    for k, name in ((3, "reward"), (4, "truncated"), (5, "terminated")):
+        assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), name
+
+
+def test_pendulum_gym_trajectories_stay_in_narrow_workgroups():
+    B, K = 1 << 20, 4
+    env, props, keep, spec = make_env("pendulum", B, torch.float32, control_state=["theta"])
+    env.trajectory_pool = False
+    st = random_state("pendulum", B, np.float32, spec, seed=78)
+    acts = env.new_actions_buffer(K)
+    acts.zero_()
+    env.vmap_sim_ahead(to_state(env, st, reference={"theta": np.zeros(B, np.float32)}), acts, env.tau, env.tau, return_rew_trunc_term=True)
+    torch.cuda.synchronize()
+    assert _native.last_launch() == "sim_ahead_kernel (lean, gym outputs)"

@@ -20,6 +20,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--calls", type=int, default=20)
 ap.add_argument("--action-layout", default="lane_major")
 ap.add_argument("--obs-only", action="store_true")
+ap.add_argument("--gym", action="store_true", help="with the fused reward / terminated / truncated trajectories")
 ap.add_argument("names", nargs="*")
 a = ap.parse_args()
 
@@ -45,7 +46,7 @@ env, state, actions, B, Kc, *_ = bench.build_env(ba, torch.device("cuda", 0), 0)
 
 
 def call():
-    return env.vmap_sim_ahead(state, actions, env.tau, env.tau)
+    return env.vmap_sim_ahead(state, actions, env.tau, env.tau, return_rew_trunc_term=a.gym)
 
 
 for _ in range(40):
