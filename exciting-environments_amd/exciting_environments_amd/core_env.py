@@ -1022,6 +1022,7 @@ class CoreEnvironment(ABC):
 
     _PLACEMENT_REPLACEMENTS = 2
     _REPLACE_RATIO = 1.05  # a pooled set this much slower than its sibling in real launches is up for replacement
+    _REPLACE_DECIDE_USES = 3  # ... but only while it has been timed at most this often: afterwards it stays (no search in a long run)
     _PLACEMENT_SPACER_BYTES = 16 << 30  # a rejected block + this much memory stay allocated while the next block is made
 
     # Round 4: a placement can be judged ABSOLUTELY. Over twelve placements of one process (tools/placement_classify.py) the
@@ -1184,7 +1185,10 @@ class CoreEnvironment(ABC):
                 return False
             ms = [t.steady_ms for t in sets]
             big = key[1] * (key[2] + key[3]) * key[0] * (4 if key[5] is torch.float32 else 8) >= (1 << 30)  # only such sets are replaced
-            if big and max(ms) > self._REPLACE_RATIO * min(ms) and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS:
+            # a set can only be replaced during its first _REPLACE_DECIDE_USES timed launches: until every set is past that window
+            # (or the replacements of the shape are used up) a later call may still run a placement search
+            if (big and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS
+                    and any(t.uses <= self._REPLACE_DECIDE_USES for t in sets)):
                 return False
         return True
 
@@ -1239,6 +1243,7 @@ class CoreEnvironment(ABC):
                     best = min(sib) if sib else self._placement_best.get(pkey)
                     ms = ts.steady_ms if (sib and ts.steady_ms is not None) else (ts.placement or {}).get("chosen_ms")
                     if (best is not None and ms is not None and ms > self._REPLACE_RATIO * best and (OW + S) * rows * B * isz >= (1 << 30)
+                            and ts.uses <= self._REPLACE_DECIDE_USES  # decided early, never in the middle of a long run
                             and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS and launch is not None
                             and self.trajectory_placement in ("auto", "search")):
                         self._placement_replaced[key] = self._placement_replaced.get(key, 0) + 1
