@@ -381,12 +381,12 @@ def sim_ahead(env_id, solver_id, dtype, B, K, substeps, props: Props, control: O
 
 def sim_ahead_raw(env_id, solver_id, dtype_code, B, K, substeps, props_ref, control_ref, obs_stepsize, env_tau, in_ptrs,
                   actions_ptr, action_layout, obs_ptr, traj_ptrs, traj_layout, last_ptrs, semantics, ws_ptr, ws_bytes, opts_ref,
-                  stream):
+                  stream, gym_ref=None):
     """excenv_sim_ahead_ws with every argument already in its C form (the fast path of vmap_sim_ahead: lane-major
-    trajectories, no gym outputs). The caller has made the buffers' device current."""
+    trajectories; gym_ref: None or byref(TrajGym)). The caller has made the buffers' device current."""
     rc = _lib.excenv_sim_ahead_ws(env_id, solver_id, dtype_code, B, K, substeps, props_ref, control_ref, obs_stepsize, env_tau,
                                   in_ptrs, actions_ptr, action_layout, obs_ptr, traj_ptrs, traj_layout, last_ptrs, semantics,
-                                  None, ws_ptr, ws_bytes, opts_ref, stream)
+                                  gym_ref, ws_ptr, ws_bytes, opts_ref, stream)
     if rc != 0:
         _check(rc, "excenv_sim_ahead")
 

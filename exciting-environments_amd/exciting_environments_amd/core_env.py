@@ -909,9 +909,11 @@ class CoreEnvironment(ABC):
             a_layout = _native.LAYOUT_ENV_MAJOR
 
         want_states = self.store_state_trajectory
-        if self.traj_layout == "lane_major" and not want_gym and B > 0 and self.device.type == "cuda":
+        if self.traj_layout == "lane_major" and B > 0 and self.device.type == "cuda" and not (want_gym and out is not None):
+            # (with the gym trajectories too since round 4: their launches used to write unpooled, unplaced buffers — observations
+            # and seven leaves allocated back to back, the slow placement level — and cost 5.5 ... 6.4 ms where this path gives 5.5)
             return self._run_sim_ahead_lane_major(init_state, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub,
-                                                  want_states, out)
+                                                  want_states, out, want_gym)
         if out is not None:
             raise ValueError("vmap_sim_ahead(out=...) is available for the default lane-major trajectories without gym outputs")
         isz = 4 if self.dtype is torch.float32 else 8
@@ -1474,9 +1476,10 @@ class CoreEnvironment(ABC):
     _SHARED_TRAJ_BYTES = 32 << 20
 
     def _run_sim_ahead_lane_major(self, init_state, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub,
-                                  want_states, out=None):
-        """The default layout without gym outputs: buffers carved from one or two allocations, pointers computed from the base
-        address, one ctypes call with plain arguments (same launch as the general path below)."""
+                                  want_states, out=None, want_gym=False):
+        """The default layout: buffers carved from one or two allocations, pointers computed from the base address, one ctypes call
+        with plain arguments (same launch as the general path above). want_gym: the reward / terminated / truncated trajectories
+        come from the same launch into arrays of their own (returned as a fifth element)."""
         S, OW = self.physical_state_dim, self._obs_dim()
         N = K * sub
         rows = N + 1
@@ -1515,6 +1518,17 @@ class CoreEnvironment(ABC):
         sem = _native.SEM_AHEAD if self.sim_ahead_semantics == "ahead" else _native.SEM_STEP
         st_in_ptrs = _native._ptrs(st_in)
 
+        gym_out = gym_ref = None
+        if want_gym:  # excenv_traj_gym_t, lane-major: reward / terminated [N][B], truncated [N + 1][TW][B]
+            TW = _native.truncated_width(self.ENV_ID, len(self.control_state))
+            rew = torch.empty((N, B), dtype=dt, device=dev)
+            term = torch.empty((N, B), dtype=torch.bool, device=dev)
+            trunc = torch.empty((N + 1, TW, B), dtype=torch.bool, device=dev)
+            gym_out = (rew.t()[..., None], trunc.permute(2, 0, 1), term.t()[..., None])
+            gym_struct = _native.TrajGym(rew.data_ptr(), term.data_ptr(), trunc.data_ptr())
+            gym_ref = ctypes.byref(gym_struct)
+        done = (lambda *r: r + (gym_out,)) if want_gym else (lambda *r: r)
+
         def launch(o_ptr, t_ptrs, l_ptrs):  # the trajectory launch of this call into the given output buffers
             with _native._on_device(dev):
                 _native.sim_ahead_raw(self.ENV_ID, self._solver.id, 0 if dt is torch.float32 else 1, B, K, sub, ctypes.byref(props),
@@ -1522,7 +1536,7 @@ class CoreEnvironment(ABC):
                                       st_in_ptrs, actions.data_ptr() if K > 0 else None, a_layout, o_ptr,
                                       t_ptrs if want_states else None, _native.LAYOUT_LANE_MAJOR, l_ptrs, sem, ws_ptr,
                                       ws_bytes if ws_ptr is not None else 0, None if opts is None else ctypes.byref(opts),
-                                      _native._raw_stream(dev))
+                                      _native._raw_stream(dev), gym_ref)
 
         if out is not None:
             # the caller hands back what an earlier call of the same shape returned: same buffers, no allocation
@@ -1571,9 +1585,9 @@ class CoreEnvironment(ABC):
             obs_ptr, traj_ptrs, last_ptrs = ts.obs_ptr, ts.traj_ptrs, ts.last_ptrs
             self._pool_drain_waits()
             self._traj_timed_launch(ts, lambda: launch(obs_ptr, traj_ptrs, last_ptrs), (OW + (S if want_states else 0)) * rows * B * isz)
-            return observations, st_views, last, N
+            return done(observations, st_views, last, N)
         launch(obs_ptr, traj_ptrs, last_ptrs)
-        return observations, st_views, last, N
+        return done(observations, st_views, last, N)
 
     def _traj_state(self, init_state, st_views, lead_shape, N):
         """Rebuild the State pytree of a trajectory: reference / PRNGKey broadcast along the saved rows,
