@@ -167,8 +167,20 @@ template <> struct VecOf<float, 4> { using type = float4; };
 template <> struct VecOf<double, 1> { using type = double; };
 template <> struct VecOf<double, 2> { using type = double2; };
 
+// V * sizeof(T) > 16 ("double-wide" lanes, round 4): the lane's environments are TWO (or more) groups of 16 / sizeof(T), one wave's
+// worth of groups apart — every access instruction of the wave still covers one contiguous 1 KiB run, and the runs of its groups are
+// adjacent: 2 KiB per wave, stream and row (the sweep's "vpl2" shape, profiles/r04_pattern_sweep.md). p points at the lane's first group.
 template <typename T, int V> __device__ __forceinline__ void load_v(const T* p, T (&out)[V]) {
-  if constexpr (V == 1) {
+  if constexpr (V * sizeof(T) > 16) {
+    constexpr int VE = 16 / (int)sizeof(T);
+#pragma unroll
+    for (int g = 0; g < V / VE; ++g) {
+      T tmp[VE];
+      load_v<T, VE>(p + g * (64 * VE), tmp);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) out[g * VE + j] = tmp[j];
+    }
+  } else if constexpr (V == 1) {
     out[0] = *p;
   } else {
     using VT = typename VecOf<T, V>::type;
@@ -179,7 +191,16 @@ template <typename T, int V> __device__ __forceinline__ void load_v(const T* p, 
   }
 }
 template <typename T, int V> __device__ __forceinline__ void store_v(T* p, const T (&in)[V]) {
-  if constexpr (V == 1) {
+  if constexpr (V * sizeof(T) > 16) {
+    constexpr int VE = 16 / (int)sizeof(T);
+#pragma unroll
+    for (int g = 0; g < V / VE; ++g) {
+      T tmp[VE];
+#pragma unroll
+      for (int j = 0; j < VE; ++j) tmp[j] = in[g * VE + j];
+      store_v<T, VE>(p + g * (64 * VE), tmp);
+    }
+  } else if constexpr (V == 1) {
     *p = in[0];
   } else {
     using VT = typename VecOf<T, V>::type;
@@ -193,6 +214,17 @@ template <typename T, int V> __device__ __forceinline__ void store_v(T* p, const
 
 // Trajectory rows are written once and never read back by the kernel: optional streaming (nt) stores.
 template <typename T, int V> __device__ __forceinline__ void store_stream(T* p, const T (&in)[V]) {
+  if constexpr (V * sizeof(T) > 16) {
+    constexpr int VE = 16 / (int)sizeof(T);
+#pragma unroll
+    for (int g = 0; g < V / VE; ++g) {
+      T tmp[VE];
+#pragma unroll
+      for (int j = 0; j < VE; ++j) tmp[j] = in[g * VE + j];
+      store_stream<T, VE>(p + g * (64 * VE), tmp);
+    }
+    return;
+  }
 #if EXCENV_NT_STORES
   if constexpr (V == 1) {
     *p = in[0];  // V == 1 also serves the env-major layout, whose scattered words must merge in L2: no nt
@@ -458,8 +490,10 @@ __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
   static_assert(!AEM || (!GENERAL && !M::HAS_LUT && aem_shape_ok<T, V>() && (16 / (int)sizeof(T)) % A == 0),
                 "row-major actions are fused into the widest lean instantiation only");
   const int64_t blk0 = (int64_t)blockIdx.x * (NT * V);  // first env of this workgroup
-  const unsigned lane_env = threadIdx.x * V;
-  const int64_t i0 = blk0 + lane_env;
+  constexpr bool DOUBLE_WIDE = V * sizeof(T) > 16;  // the lane's environments in groups one wave's width apart (load_v / store_v)
+  static_assert(!DOUBLE_WIDE || (!GENERAL && !AEM && !LGYM && !M::HAS_LUT), "double-wide lanes: plain lean instantiations only");
+  const unsigned lane_env = DOUBLE_WIDE ? (threadIdx.x >> 6) * (64u * V) + (threadIdx.x & 63u) * (unsigned)(16 / sizeof(T)) : threadIdx.x * V;
+  const int64_t i0 = blk0 + lane_env;  // double-wide: the host launches whole waves only (B % (64 V) == 0)
   Ctx<T, M> cs[NC];
 #pragma unroll
   for (int v = 0; v < NC; ++v) {

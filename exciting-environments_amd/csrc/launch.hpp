@@ -362,6 +362,9 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
 // the small models, BLOCK everywhere else — measured per workload (profiles/r04_pattern_sweep.md): pendulum Euler fp32 -10.6 %, fp64
 // -8 %, MSD Euler fp32 -7 %, fp64 -6 %, tank Euler fp32 -6 % (fp64 +3 %: not taken); RK4 / Tsit5 of the same models +3 ... +9 %,
 // cart-pole / acrobot Euler within 3 % either way, PMSM (256 registers) not possible.
+#ifndef EXCENV_DOUBLE_WIDE_RULE  // which (model, dtype, solver) take double-wide lanes; a macro so that A/B builds can widen it
+#define EXCENV_DOUBLE_WIDE_RULE(M, T, solver) false
+#endif
 #ifndef EXCENV_ROW_SYNC_MIN_BATCH
 #define EXCENV_ROW_SYNC_MIN_BATCH ((int64_t)1 << 17)
 #endif
@@ -371,6 +374,12 @@ static inline int row_sync_mode() {  // EXCENV_ROW_SYNC = 0: off, 1: barrier onl
   return mode;
 }
 static inline bool row_sync_enabled() { return row_sync_mode() != 0; }
+// Double-wide lanes (kernels.hpp load_v / store_v: 32 bytes per lane and stream as two adjacent 1 KiB runs per wave): the models
+// with few registers per environment, where the per-row barrier of the 1024-thread form does not pay (RK4 / Tsit5) or does not
+// apply. Measured per workload (profiles/r04_pattern_sweep.md §4).
+template <class M, typename T> constexpr bool sim_double_wide_ok(int solver) {
+  return !M::HAS_LUT && !M::IS_PMSM && EXCENV_DOUBLE_WIDE_RULE(M, T, solver);
+}
 constexpr int WIDE_THREADS = 1024;
 constexpr int64_t WIDE_MIN_WORKGROUPS = 256;  // at least one wide workgroup per CU of the MI355X, else the narrow form fills the chip better
 template <class M, typename T> constexpr bool sim_wide_ok(int solver) {
@@ -436,6 +445,13 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
   if (general) {
     if (ka.truncated == nullptr) EXCENV_SIM_LAUNCH(true, 1, -2);  // no gym trajectories: the instantiation without their code
     EXCENV_SIM_LAUNCH(true, 1, -1);
+  }
+  if constexpr (sim_double_wide_ok<M, T>(SOLVER)) {
+    constexpr int VD = 32 / (int)sizeof(T);
+    if (V == VD) {
+      if (ka.straj[0] == nullptr) EXCENV_SIM_LAUNCH(false, VD, 0);
+      EXCENV_SIM_LAUNCH(false, VD, 1);
+    }
   }
   if (ka.straj[0] == nullptr) {  // observations only: its own instantiations (no state stores between the action loads and their waits)
     if constexpr (sizeof(T) == 4) {
@@ -646,6 +662,10 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     while (want > 1 && (sc.B % want) != 0) want >>= 1;
     V = want;
   }
+  // double-wide lanes: whole waves only, enough of them to fill the chip twice over, nothing else special about the call
+  if (sim_double_wide_ok<M, T>(sc.solver) && vec_ok && V == VMAX && sc.vec_pref == 0 && !general && !aem && !lean_gym && !tiled_a && !tiled_t &&
+      (sc.B % (64 * 2 * VMAX)) == 0 && sc.B / (2 * VMAX) >= (int64_t)BLOCK * 2 * 256)
+    V = 2 * VMAX;
   if (lean_gym && (general || V != VMAX)) { set_error("excenv_sim_ahead: internal error: lean gym outputs need %d environments per lane", VMAX); return EXCENV_EINVAL; }
   if (aem && V != VMAX) { set_error("excenv_sim_ahead: internal error: fused row-major actions need %d environments per lane", VMAX); return EXCENV_EINVAL; }
   if (tiled_a || tiled_t) {  // a workgroup must not straddle tiles
@@ -701,7 +721,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
   }
 #undef EXCENV_SIM_CASE
-  g_last_launch = general ? "sim_ahead_kernel (general)" : (lean_gym ? (nt > BLOCK ? "sim_ahead_kernel (lean, gym outputs, 1024 threads)" : "sim_ahead_kernel (lean, gym outputs)") : aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? (nt > BLOCK ? "sim_ahead_kernel (V=2, 1024 threads)" : "sim_ahead_kernel (V=2)") : (nt > BLOCK ? "sim_ahead_kernel (V=4, 1024 threads)" : "sim_ahead_kernel (V=4)"))));
+  g_last_launch = general ? "sim_ahead_kernel (general)" : (lean_gym ? (nt > BLOCK ? "sim_ahead_kernel (lean, gym outputs, 1024 threads)" : "sim_ahead_kernel (lean, gym outputs)") : aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? (nt > BLOCK ? "sim_ahead_kernel (V=2, 1024 threads)" : "sim_ahead_kernel (V=2)") : (V > VMAX ? (V == 8 ? "sim_ahead_kernel (V=8, double-wide)" : "sim_ahead_kernel (V=4, double-wide)") : (nt > BLOCK ? "sim_ahead_kernel (V=4, 1024 threads)" : "sim_ahead_kernel (V=4)")))));
   if (int rc = check_launch("excenv_sim_ahead")) return rc;
   if (split_control && !general) {
     ControlFillArgs<T, M> fa;
