@@ -143,3 +143,28 @@ def test_pendulum_gym_trajectories_stay_in_narrow_workgroups():
     env.vmap_sim_ahead(to_state(env, st, reference={"theta": np.zeros(B, np.float32)}), acts, env.tau, env.tau, return_rew_trunc_term=True)
     torch.cuda.synchronize()
     assert _native.last_launch() == "sim_ahead_kernel (lean, gym outputs)"
+
+
+@pytest.mark.parametrize("env_name,control", [("pendulum", ["theta", "omega"]), ("mass_spring_damper", ["deflection"])])
+def test_control_columns_behind_wide_workgroups_equal_one_environment_per_lane(env_name, control):
+    """control_state columns alone: the 1024-thread lean kernel writes everything else into the wider observation rows and
+    control_fill_kernel fills the columns — the bits of the same call with one environment per lane (256-thread workgroups whose rows
+    leave through LDS at this batch size, kernels.hpp row_sync == 2, and the same fill kernel behind them)."""
+    B, K = 1 << 20, 7
+    env, props, keep, spec = make_env(env_name, B, torch.float32, control_state=list(control))
+    env.trajectory_pool = False
+    st = random_state(env_name, B, np.float32, spec, seed=79)
+    rng = np.random.default_rng(80)
+    refs = {n: rng.uniform(*[float(np.min(x)) for x in spec["phys_norm"][n]], B).astype(np.float32) for n in control}
+    acts = env.new_actions_buffer(K)
+    acts.copy_(torch.as_tensor(rng.uniform(-1, 1, (B, K, 1)).astype(np.float32), device=env.device))
+    outs = {}
+    for vec in (4, 1):
+        env.launch_opts = _native.launch_opts(envs_per_lane=vec) if vec == 1 else None
+        outs[vec] = env.vmap_sim_ahead(to_state(env, st, reference=refs), acts, env.tau, env.tau)
+        torch.cuda.synchronize()
+        assert _native.last_launch() == ("sim_ahead_kernel (V=4, 1024 threads)" if vec == 4 else "sim_ahead_kernel (V=1)")
+    a, b = outs[4], outs[1]
+    assert a[0].shape[-1] == len(env.obs_description) and torch.equal(a[0], b[0])
+    for n in env.STATE_FIELDS:
+        assert torch.equal(getattr(a[1].physical_state, n), getattr(b[1].physical_state, n)), n
