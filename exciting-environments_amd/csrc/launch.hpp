@@ -658,6 +658,11 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
       const int cap = (sc.solver == EXCENV_EULER) ? 2 : 1;
       if (want > cap) want = cap;
     }
+    // PMSM observations only in fp32: the arithmetic of a step is the full launch's, the bytes are 40 of 68 — VALU floor and memory
+    // floor meet (2.7 / 2.8 ms) and what counts is how well they overlap: two environments per lane (116 registers, four waves
+    // per SIMD) instead of four (186, two waves). Same-buffers A/B: Euler 3.555 -> 3.157 ms (0.59 -> 0.66 of the roof), RK4 4.457 ->
+    // 4.010, Tsit5 5.435 -> 4.784; with full outputs four stay faster (RK4 5.64 vs 6.19, Tsit5 6.25 vs 6.37).
+    if (sc.vec_pref == 0 && M::IS_PMSM && !M::HAS_LUT && sizeof(T) == 4 && ka.straj[0] == nullptr && !aem && !lean_gym && want > 2) want = 2;
     if (want > VMAX) want = VMAX;
     while (want > 1 && (sc.B % want) != 0) want >>= 1;
     V = want;

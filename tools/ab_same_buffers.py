@@ -25,7 +25,8 @@ ap.add_argument("names", nargs="*")
 a = ap.parse_args()
 
 base_path = _native.library_path()
-libs = [("in-tree", base_path)] + [(n, os.path.join(ROOT, "ab_libs", f"libexcenv_{n}.so")) for n in a.names]
+# a name of the form vec=N is not another library but the in-tree one with N environments per lane (launch option)
+libs = [("in-tree", base_path)] + [(n, base_path if n.startswith("vec=") else os.path.join(ROOT, "ab_libs", f"libexcenv_{n}.so")) for n in a.names]
 
 
 def use(path):
@@ -61,6 +62,7 @@ res = {n: [] for n, _ in libs}
 for r in range(a.rounds):
     for n, p in libs:
         use(p)
+        env.launch_opts = _native.launch_opts(envs_per_lane=int(n[4:])) if n.startswith("vec=") else None
         for _ in range(4):
             out = call()
             del out
