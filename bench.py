@@ -62,6 +62,11 @@ WORKLOADS = {
     "cartpole_tsit5_f32": ("CART_POLE", "tsit5", torch.float32, 2e-2, 22, 100),
     "cartpole_euler_f64": ("CART_POLE", "euler", torch.float64, 2e-2, 21, 100),
     "acrobot_euler_f64": ("ACROBOT", "euler", torch.float64, 1e-3, 21, 100),
+    "cartpole_rk4_f32": ("CART_POLE", "rk4", torch.float32, 2e-2, 22, 100),
+    "cartpole_tsit5_f64": ("CART_POLE", "tsit5", torch.float64, 2e-2, 21, 100),
+    "acrobot_rk4_f32": ("ACROBOT", "rk4", torch.float32, 1e-3, 22, 100),
+    "pendulum_tsit5_f64": ("PENDULUM", "tsit5", torch.float64, 2e-2, 21, 100),
+    "msd_rk4_f32": ("MASS_SPRING_DAMPER", "rk4", torch.float32, 1e-4, 22, 100),
 }
 ORACLE_NAME = {"PMSM": "pmsm", "PENDULUM": "pendulum", "MASS_SPRING_DAMPER": "mass_spring_damper", "CART_POLE": "cartpole",
                "ACROBOT": "acrobot", "FLUID_TANK": "fluid_tank"}

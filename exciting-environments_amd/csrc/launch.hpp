@@ -407,7 +407,8 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
     }
   }
   if constexpr (!M::HAS_LUT) {
-    if (lgym) {  // the gym trajectories out of the widest lean form (V == 16 / sizeof(T))
+    if (lgym) {  // the gym trajectories out of the widest lean form (V == 16 / sizeof(T)); half of it (two environments per lane in
+      // fp32) was built and measured in round 4: PMSM 5.80 -> 7.26 ms, cart-pole 3.55 -> 4.34, acrobot 3.55 -> 4.11 — removed
       constexpr int VA = 16 / (int)sizeof(T);
       if constexpr (sim_wide_gym_ok<M, T>(SOLVER)) {
         if (nt == WIDE_THREADS) {
@@ -663,6 +664,12 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     // per SIMD) instead of four (186, two waves). Same-buffers A/B: Euler 3.555 -> 3.157 ms (0.59 -> 0.66 of the roof), RK4 4.457 ->
     // 4.010, Tsit5 5.435 -> 4.784; with full outputs four stay faster (RK4 5.64 vs 6.19, Tsit5 6.25 vs 6.37).
     if (sc.vec_pref == 0 && M::IS_PMSM && !M::HAS_LUT && sizeof(T) == 4 && ka.straj[0] == nullptr && !aem && !lean_gym && want > 2) want = 2;
+    // cart-pole RK4 / Tsit5 and pendulum Tsit5 in fp32: the same trade (registers for a resident wave) — same-buffers A/B with two
+    // instead of four environments per lane: cart-pole RK4 4.646 -> 4.323 ms, Tsit5 7.046 -> 6.091, pendulum Tsit5 2.637 -> 2.477
+    // (pendulum RK4, mass-spring-damper, tank: four stay faster or equal)
+    if (sc.vec_pref == 0 && sizeof(T) == 4 && !aem && !lean_gym && want > 2 &&
+        ((M::ID == EXCENV_CART_POLE && sc.solver != EXCENV_EULER) || (M::ID == EXCENV_PENDULUM && sc.solver == EXCENV_TSIT5)))
+      want = 2;
     if (want > VMAX) want = VMAX;
     while (want > 1 && (sc.B % want) != 0) want >>= 1;
     V = want;
