@@ -68,6 +68,7 @@ static inline bool aem_enabled() {
   return on != 0;
 }
 static inline int auto_envs_per_lane(int64_t B, int vmax);
+static inline bool widest_form_pays(int64_t B, int vmax);
 static inline bool aem_applies(int env_id, bool has_lut, bool general, int A, size_t elem, int64_t B, int64_t K, int solver,
                                int vec_pref, int action_layout, int traj_layout, int flags, const void* actions) {
   const int vmax = 16 / (int)elem;
@@ -78,7 +79,7 @@ static inline bool aem_applies(int env_id, bool has_lut, bool general, int A, si
   if ((reinterpret_cast<uintptr_t>(actions) & 15u) != 0) return false;
   if ((int64_t)EXCENV_BLOCK * vmax * K * A >= ((int64_t)1 << 32)) return false;             // 32-bit element offsets inside a workgroup
   // only where the batch takes the widest form anyway (launch_sim picks the same way)
-  int want = vec_pref > 0 ? vec_pref : auto_envs_per_lane(B, vmax);
+  int want = vec_pref > 0 ? vec_pref : (widest_form_pays(B, vmax) ? vmax : 1);
   if (vec_pref == 0 && env_id == EXCENV_ACROBOT && solver != EXCENV_EULER && want > 2) want = 2;
   return want == vmax;
 }
@@ -284,11 +285,17 @@ template <class M> static int pmsm_coef(const excenv_props_t* p, double env_tau,
 // Envs per lane for a batch: the widest 16-byte form that still leaves at least one wave per SIMD on the chip
 // (256 CUs x 4 SIMDs = 1024 waves of 64 lanes); small batches run one env per lane so that the per-step dependent chain
 // of a wave is as short as possible (batch sweep).
+// Environments per lane by batch size. Two per lane from one wave per SIMD on the chip (1024 SIMDs x 64 lanes), FOUR only from two
+// waves per SIMD: at B = 2^18 four per lane leave one 256-thread workgroup per CU — round 4, same-buffers A/B and fresh processes:
+// PMSM Euler 0.411 -> 0.325 ms with two per lane, pendulum 1.259 -> 0.963, cart-pole 0.228 -> 0.153; from 2^19 on four win.
 static inline int auto_envs_per_lane(int64_t B, int vmax) {
   int v = vmax;
-  while (v > 1 && (B / v) < (int64_t)1024 * 64) v >>= 1;
+  while (v > 1 && (B / v) < (int64_t)1024 * 64 * (v >= 4 ? 2 : 1)) v >>= 1;
   return v;
 }
+// The forms that exist only at the widest lane width (row-major actions read by the kernel, lean gym outputs) keep the earlier bound:
+// they beat what the call would fall back to (a transposition pass, the one-environment general kernel) from one wave per SIMD on.
+static inline bool widest_form_pays(int64_t B, int vmax) { return (B / vmax) >= (int64_t)1024 * 64; }
 
 template <class M, typename T> static int launch_step(const StepCall& sc) {
   StepArgs<T, M> ka;
@@ -494,7 +501,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   constexpr int VMAXG = 16 / (int)sizeof(T);
   bool lean_gym = with_gym && !batched && !M::HAS_LUT && ka.n_control <= M::S && sc.action_layout == EXCENV_LAYOUT_LANE_MAJOR &&
                   sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR && sc.B > 0 && (sc.B % VMAXG) == 0 &&
-                  (sc.vec_pref > 0 ? sc.vec_pref == VMAXG : auto_envs_per_lane(sc.B, VMAXG) == VMAXG) &&
+                  (sc.vec_pref > 0 ? sc.vec_pref == VMAXG : widest_form_pays(sc.B, VMAXG)) &&
                   aligned16(sc.gym->reward) && ((uintptr_t)sc.gym->terminated % VMAXG) == 0 && ((uintptr_t)sc.gym->truncated % VMAXG) == 0;
   for (int j = 0; lean_gym && j < ka.n_control; ++j) lean_gym = sc.control->reference[j] != nullptr && aligned16(sc.control->reference[j]);
   // the four-leaf models in fp64 with an RK solver would need more than 256 registers in that form (one wave per SIMD): general
@@ -648,7 +655,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   int V = 1;
   if (general) vec_ok = false;  // one environment per lane (two, each with its own property set, measured no faster: DESIGN.md §4.1)
   if (vec_ok) {
-    int want = sc.vec_pref > 0 ? sc.vec_pref : auto_envs_per_lane(sc.B, VMAX);
+    int want = sc.vec_pref > 0 ? sc.vec_pref : ((aem || lean_gym) ? VMAX : auto_envs_per_lane(sc.B, VMAX));
     // acrobot RK4 / Tsit5 is VALU-bound with the largest register footprint of all instantiations: two envs per lane keep
     // a third wave per SIMD resident (measured +7 % over four)
     if (sc.vec_pref == 0 && M::ID == EXCENV_ACROBOT && sc.solver != EXCENV_EULER && want > 2) want = 2;
