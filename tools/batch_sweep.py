@@ -26,9 +26,11 @@ for lb in args.log2:
     acts = env.new_actions_buffer(K)
     acts.uniform_(-1, 1)
     s = st
-    for _ in range(3):
+    for it in range(40):  # large batches: until the pooled output sets are made, placed and past their replacement window
         o, _, s = env.vmap_sim_ahead(s, acts, env.tau, env.tau)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        if it >= 2 and env.trajectory_placement_settled:
+            break
     n = max(5, min(200, (1 << 24) // B))
     t0 = time.perf_counter()
     for _ in range(n):
