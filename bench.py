@@ -557,7 +557,8 @@ def main():
     if traffic is None and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            key = f"{args.workload}|B={B}|chunk={Kc}|{args.traj_layout}" + ("|step" if args.path == "step" else "")
+            key = (f"{args.workload}|B={B}|chunk={Kc}|{args.traj_layout}" + ("|step" if args.path == "step" else "")
+                   + ("|obs_only" if args.obs_only else ""))  # (no committed PMC pass for observations-only launches: traffic stays null)
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
                 traffic_source = ("replayed from profiles/traffic.json (" + tj[key].get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
