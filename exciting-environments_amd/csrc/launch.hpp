@@ -387,6 +387,10 @@ static inline bool row_sync_enabled() { return row_sync_mode() != 0; }
 template <class M, typename T> constexpr bool sim_double_wide_ok(int solver) {
   return !M::HAS_LUT && !M::IS_PMSM && EXCENV_DOUBLE_WIDE_RULE(M, T, solver);
 }
+static inline bool wide_enabled() {  // EXCENV_WIDE=0: the 256-thread form everywhere (A/B measurements, counter passes)
+  static const int on = [] { const char* e = std::getenv("EXCENV_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
 constexpr int WIDE_THREADS = 1024;
 constexpr int64_t WIDE_MIN_WORKGROUPS = 256;  // at least one wide workgroup per CU of the MI355X, else the narrow form fills the chip better
 template <class M, typename T> constexpr bool sim_wide_ok(int solver) {
@@ -709,7 +713,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     if (bytes <= ((size_t)64 << 10)) { ka.row_sync = 2; row_lds = bytes; }
   }
   int nt = BLOCK;
-  if (sim_wide_ok<M, T>(sc.solver) && (!lean_gym || sim_wide_gym_ok<M, T>(sc.solver)) && !general && !aem && !tiled_a && !tiled_t && V == VMAX &&
+  if (wide_enabled() && sim_wide_ok<M, T>(sc.solver) && (!lean_gym || sim_wide_gym_ok<M, T>(sc.solver)) && !general && !aem && !tiled_a && !tiled_t && V == VMAX &&
       sc.B / V >= WIDE_THREADS * WIDE_MIN_WORKGROUPS)
     nt = WIDE_THREADS;
   {  // element offset of workgroup w's first env in each stream
