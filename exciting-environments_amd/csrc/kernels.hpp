@@ -681,7 +681,11 @@ __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
 #pragma unroll
           for (int j = 0; j < S; ++j) buf[(OWr + j) * NT + threadIdx.x] = sv[0][j];
         }
-        __builtin_amdgcn_s_barrier();  // (LDS writes above are waited for by the compiler's s_waitcnt before the barrier)
+        // this wave's LDS writes must have landed before it signals: gfx950 backs barriers off instead of waiting implicitly, and the
+        // compiler adds no wait in front of the raw builtin (the disassembly showed ds_write ...; s_barrier). lgkmcnt only — a
+        // __syncthreads() would also drain the trajectory stores still in flight (vmcnt), which is what this path must not do
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const unsigned ln = threadIdx.x & 63u;
         for (int u = wv; u < NS * CH; u += NW) {
