@@ -20,6 +20,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--calls", type=int, default=20)
 ap.add_argument("--action-layout", default="lane_major")
 ap.add_argument("--obs-only", action="store_true")
+ap.add_argument("--traj-layout", default="lane_major", help="env_major: the reference's row-major output arrays (register-ring kernel)")
 ap.add_argument("--batch", type=int, default=0, help="log2 of the batch size (default: the workload's)")
 ap.add_argument("--gym", action="store_true", help="with the fused reward / terminated / truncated trajectories")
 ap.add_argument("names", nargs="*")
@@ -42,7 +43,7 @@ class Args:
 
 
 ba = Args()
-ba.workload, ba.batch, ba.chunk, ba.semantics, ba.traj_layout, ba.action_layout = a.workload, (1 << a.batch) if a.batch else 0, 0, "ahead", "lane_major", a.action_layout
+ba.workload, ba.batch, ba.chunk, ba.semantics, ba.traj_layout, ba.action_layout = a.workload, (1 << a.batch) if a.batch else 0, 0, "ahead", a.traj_layout, a.action_layout
 ba.path, ba.obs_only, ba.no_workspace, ba.no_fused, ba.no_pool = "sim_ahead", a.obs_only, False, False, False
 env, state, actions, B, Kc, *_ = bench.build_env(ba, torch.device("cuda", 0), 0)
 
