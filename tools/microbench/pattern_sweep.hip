@@ -180,14 +180,16 @@ int main(int argc, char** argv) {
   }
   g_a0 = act; g_a1 = act + (int64_t)K * B; g_t0 = obs; g_t1 = st;
 
-  auto headline = [&](int order, int layout = 0) {  // layout 1: observations as [8][K+1][B] (every component its own stream)
+  // pad: extra floats per row of every stream (row pitch B + pad): the streams' rows are then no longer 16 MiB multiples apart
+  auto headline = [&](int order, int layout = 0, int64_t pad = 0) {  // layout 1: observations as [8][K+1][B] (every component its own stream)
     Streams s{};
     s.nr = 2;
     for (int r = 0; r < 2; ++r) { s.rd[r] = act + (int64_t)r * K * B; s.rd_rs[r] = B; }  // lane-major actions [A][K][B]-like: two streams
     s.nw = 15;
     float* w[15]; int64_t rs[15];
-    for (int c = 0; c < 8; ++c) { w[c] = layout ? obs + (int64_t)c * ROWS * B : obs + (int64_t)c * B; rs[c] = layout ? B : 8 * B; }
-    for (int j = 0; j < 7; ++j) { w[8 + j] = st + (int64_t)j * ROWS * B; rs[8 + j] = B; }
+    const int64_t BP = B + pad;
+    for (int c = 0; c < 8; ++c) { w[c] = layout ? obs + (int64_t)c * ROWS * BP : obs + (int64_t)c * BP; rs[c] = layout ? BP : 8 * BP; }
+    for (int j = 0; j < 7; ++j) { w[8 + j] = st + (int64_t)j * ROWS * BP; rs[8 + j] = BP; }
     if (order == 0) for (int q = 0; q < 15; ++q) { s.wr[q] = w[q]; s.wr_rs[q] = rs[q]; }
     else {
       int o = 0, j = 8, q = 0;
@@ -216,6 +218,10 @@ int main(int argc, char** argv) {
   add("occ2 wg256 (8 waves per CU)", 256, 1, 1, 0, 2, headline(0), HB);
   add("occ4 wg256 (16 waves per CU)", 256, 1, 1, 0, 4, headline(0), HB);
   add("occ1 wg1024 (16 waves per CU)", 1024, 1, 1, 0, 1, headline(0), HB);
+  add("row pitch + 4 KiB", 256, 1, 1, 0, 0, headline(0, 0, 1024), HB);
+  add("row pitch + 68 KiB", 256, 1, 1, 0, 0, headline(0, 0, 17 * 1024), HB);
+  add("row pitch + 1 MiB + 4 KiB", 256, 1, 1, 0, 0, headline(0, 0, 262144 + 1024), HB);
+  add("row pitch + 2 MiB", 256, 1, 1, 0, 0, headline(0, 0, 524288), HB);
   add("wg512 sync per row", 512, 1, 1, 1, 0, headline(0), HB);
   add("vpl2 sync per row", 256, 2, 1, 1, 0, headline(0), HB);
   add("obs [8][K+1][B] (component-major observations)", 256, 1, 1, 0, 0, headline(0, 1), HB);
