@@ -6,6 +6,8 @@
 #include <dlfcn.h>
 #include "launch.hpp"
 
+static_assert(EXCENV_FAULT == 0, "EXCENV_FAULT builds exist for tools/isa_guards_selftest.sh only (single objects, never linked into the library)");
+
 namespace excenv {
 
 static thread_local char g_err[512] = "";

@@ -16,14 +16,12 @@ namespace excenv {
 #define EXCENV_PINGPONG 1  // bit 0: Euler, bit 1: RK4 / Tsit5 — K loop unrolled by two with ping-pong action registers
 #endif                      // (2-step prefetch distance, 2x loop code). Measured: +3.5 % Euler, -5 % Tsit5.
 constexpr int BLOCK = EXCENV_BLOCK;
-// Experiment switch (profiles/r04_pattern_sweep.md): a workgroup barrier before the stores of every row. The no-arithmetic access
-// pattern gains 3 % (256 threads) ... 6.6 % (1024 threads) from waves that store a stream's run together; the real kernel LOSES
-// 4.5 % (256 threads) / 2 % (512 threads, barrier) / 5 % (512 threads, no barrier) in a same-buffers A/B (tools/ab_same_buffers.py):
-// lockstep takes away the overlap of one wave's arithmetic with another's stores.
-#ifndef EXCENV_ROW_BARRIER
-#define EXCENV_ROW_BARRIER 0
+// Deliberately broken builds for the self-test of the static guards (tools/isa_guards.py, tools/isa_guards_selftest.sh): bit 0 counts
+// one store too many in the hand-written wait of the action windows, bit 1 drops the LDS wait in front of the row barrier, bit 2
+// drops the wait state between the write of M0 and the LDS-direct load. Never set in a product build (static_assert in excenv_api.hip).
+#ifndef EXCENV_FAULT
+#define EXCENV_FAULT 0
 #endif
-
 // Property leaves in kernel-argument order: P statics, S mins, S maxs, A mins, A maxs.
 template <typename T, class M> struct KProps {
   static constexpr int N = M::P + 2 * M::S + 2 * M::A;
@@ -167,20 +165,9 @@ template <> struct VecOf<float, 4> { using type = float4; };
 template <> struct VecOf<double, 1> { using type = double; };
 template <> struct VecOf<double, 2> { using type = double2; };
 
-// V * sizeof(T) > 16 ("double-wide" lanes, round 4): the lane's environments are TWO (or more) groups of 16 / sizeof(T), one wave's
-// worth of groups apart — every access instruction of the wave still covers one contiguous 1 KiB run, and the runs of its groups are
-// adjacent: 2 KiB per wave, stream and row (the sweep's "vpl2" shape, profiles/r04_pattern_sweep.md). p points at the lane's first group.
 template <typename T, int V> __device__ __forceinline__ void load_v(const T* p, T (&out)[V]) {
-  if constexpr (V * sizeof(T) > 16) {
-    constexpr int VE = 16 / (int)sizeof(T);
-#pragma unroll
-    for (int g = 0; g < V / VE; ++g) {
-      T tmp[VE];
-      load_v<T, VE>(p + g * (64 * VE), tmp);
-#pragma unroll
-      for (int j = 0; j < VE; ++j) out[g * VE + j] = tmp[j];
-    }
-  } else if constexpr (V == 1) {
+  static_assert(V * sizeof(T) <= 16, "at most one 16-byte access per lane");
+  if constexpr (V == 1) {
     out[0] = *p;
   } else {
     using VT = typename VecOf<T, V>::type;
@@ -191,16 +178,7 @@ template <typename T, int V> __device__ __forceinline__ void load_v(const T* p, 
   }
 }
 template <typename T, int V> __device__ __forceinline__ void store_v(T* p, const T (&in)[V]) {
-  if constexpr (V * sizeof(T) > 16) {
-    constexpr int VE = 16 / (int)sizeof(T);
-#pragma unroll
-    for (int g = 0; g < V / VE; ++g) {
-      T tmp[VE];
-#pragma unroll
-      for (int j = 0; j < VE; ++j) tmp[j] = in[g * VE + j];
-      store_v<T, VE>(p + g * (64 * VE), tmp);
-    }
-  } else if constexpr (V == 1) {
+  if constexpr (V == 1) {
     *p = in[0];
   } else {
     using VT = typename VecOf<T, V>::type;
@@ -214,17 +192,6 @@ template <typename T, int V> __device__ __forceinline__ void store_v(T* p, const
 
 // Trajectory rows are written once and never read back by the kernel: optional streaming (nt) stores.
 template <typename T, int V> __device__ __forceinline__ void store_stream(T* p, const T (&in)[V]) {
-  if constexpr (V * sizeof(T) > 16) {
-    constexpr int VE = 16 / (int)sizeof(T);
-#pragma unroll
-    for (int g = 0; g < V / VE; ++g) {
-      T tmp[VE];
-#pragma unroll
-      for (int j = 0; j < VE; ++j) tmp[j] = in[g * VE + j];
-      store_stream<T, VE>(p + g * (64 * VE), tmp);
-    }
-    return;
-  }
 #if EXCENV_NT_STORES
   if constexpr (V == 1) {
     *p = in[0];  // V == 1 also serves the env-major layout, whose scattered words must merge in L2: no nt
@@ -477,7 +444,7 @@ __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
   extern __shared__ __align__(16) unsigned char excenv_smem[];
   static_assert(NT == BLOCK || (!GENERAL && !AEM && !M::HAS_LUT), "wide workgroups: lean instantiations only (plain or with gym outputs)");
-  constexpr bool ROW_BARRIER = (NT > BLOCK) || (EXCENV_ROW_BARRIER != 0);
+  constexpr bool ROW_BARRIER = NT > BLOCK;  // wide workgroups: the sixteen waves store every row together
   // GENERAL stays at one environment per lane. Round 4 tried two, each with its own property set (a second Ctx in registers:
   // every leaf may differ per environment, so none can stay in SGPRs — 195 registers, two waves per SIMD): 5.91 ... 6.27 ms for one,
   // 6.02 ... 6.06 for two (tools/general_path_cost.py, two sessions) — no gain, removed. What did help is compiling the gym
@@ -490,10 +457,8 @@ __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
   static_assert(!AEM || (!GENERAL && !M::HAS_LUT && aem_shape_ok<T, V>() && (16 / (int)sizeof(T)) % A == 0),
                 "row-major actions are fused into the widest lean instantiation only");
   const int64_t blk0 = (int64_t)blockIdx.x * (NT * V);  // first env of this workgroup
-  constexpr bool DOUBLE_WIDE = V * sizeof(T) > 16;  // the lane's environments in groups one wave's width apart (load_v / store_v)
-  static_assert(!DOUBLE_WIDE || (!GENERAL && !AEM && !LGYM && !M::HAS_LUT), "double-wide lanes: plain lean instantiations only");
-  const unsigned lane_env = DOUBLE_WIDE ? (threadIdx.x >> 6) * (64u * V) + (threadIdx.x & 63u) * (unsigned)(16 / sizeof(T)) : threadIdx.x * V;
-  const int64_t i0 = blk0 + lane_env;  // double-wide: the host launches whole waves only (B % (64 V) == 0)
+  const unsigned lane_env = threadIdx.x * V;
+  const int64_t i0 = blk0 + lane_env;
   Ctx<T, M> cs[NC];
 #pragma unroll
   for (int v = 0; v < NC; ++v) {
@@ -684,7 +649,9 @@ __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
         // this wave's LDS writes must have landed before it signals: gfx950 backs barriers off instead of waiting implicitly, and the
         // compiler adds no wait in front of the raw builtin (the disassembly showed ds_write ...; s_barrier). lgkmcnt only — a
         // __syncthreads() would also drain the trajectory stores still in flight (vmcnt), which is what this path must not do
+#if !(EXCENV_FAULT & 2)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_s_barrier();
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const unsigned ln = threadIdx.x & 63u;
@@ -865,11 +832,22 @@ __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
         for (int i = 0; i < NP; ++i) {
           // Inline assembly, not __builtin_amdgcn_global_load_lds: the compiler treats an LDS-direct load as a FLAT access and puts
           // `s_waitcnt vmcnt(0)` in front of every later LDS read — that would drain the trajectory stores once per step. Hidden
-          // from it, the only wait is the counted one in load_action below. (M0 = the LDS byte address of the block; the compiler
-          // itself never uses M0 in this kernel.)
+          // from it, the only wait is the counted one in load_action below. M0 = the LDS byte address of the block: declared as
+          // clobbered, and the s_nop is the wait state gfx9-family parts need between an SALU write of M0 and an LDS-direct load
+          // (the compiler's hazard recognizer emits the same s_nop behind the builtin; it does not look inside an asm string).
+          // tests/test_host_api.py checks both in the disassembly of the built library.
           const T* src = lane_src + (uint64_t)(i * EPI * V + v) * (uint64_t)ka.a_sb;
-          asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(wave_lds + (unsigned)(v * NP + i) * AEM_BLOCK_BYTES)
-                       : "memory");
+          // (M0 is a reserved register: clang warns that it "may not be preserved"; listing it is what makes the compiler's own M0
+          // initialisations — s_set_gpr_idx, its LDS-direct loads — see this statement as a redefinition)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#if EXCENV_FAULT & 4
+          asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(wave_lds + (unsigned)(v * NP + i) * AEM_BLOCK_BYTES) : "memory", "m0");
+#else
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(wave_lds + (unsigned)(v * NP + i) * AEM_BLOCK_BYTES)
+                       : "memory", "m0");
+#endif
+#pragma clang diagnostic pop
         }
       }
     }
@@ -879,8 +857,11 @@ __global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
       const int64_t w = krow / RW;
       const unsigned r = (unsigned)(krow % RW), off = (r / SP) * 16u + (r % SP) * (unsigned)(A * sizeof(T));
       // first row of a window that was requested one row earlier: everything but the trajectory stores issued since must be back
-      // (vmcnt retires in issue order). Wave-uniform.
-      if (r == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE < 63 ? NSTORE : 63) : "memory");
+      // (vmcnt retires in issue order: with exactly NSTORE vector-memory instructions behind the fill, vmcnt(NSTORE) waits for the
+      // fill and for nothing younger; FEWER than NSTORE behind it and the wait would prove nothing — tools/isa_guards.py counts them
+      // on every path of the built code). expcnt(6) never blocks here (no exports) and marks the hand-written waits for that tool.
+      // Wave-uniform.
+      if (r == 0) asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"((NSTORE + (EXCENV_FAULT & 1)) < 63 ? (NSTORE + (EXCENV_FAULT & 1)) : 63) : "memory");
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         T rr[A];

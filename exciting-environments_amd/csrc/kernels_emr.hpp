@@ -53,22 +53,6 @@ template <class M, typename T, bool AHEAD> constexpr int emr_rows() {  // a doub
   return (emr_ring_leaves<M, AHEAD>() * 32 <= EXCENV_EMR_MAX_RING_REGS / ((int)sizeof(T) / 4) ? 128 : 64) / (int)sizeof(T);
 }
 template <class M, typename T> constexpr bool emr_supported() { return !M::HAS_LUT; }  // the look-up model keeps the LDS-ring kernel
-// LONG leaves (round 4 experiment, off by default). PMSM fp32's five ring leaves only fit as 64-byte windows, and half-line runs
-// cost more per byte than whole lines (tools/microbench/scatter_runs.hip: 3.2 against 5.3 TB/s), so a leaf may take windows twice
-// as long: EXCENV_EMR_LONG = 1: i_d, i_q (2 x 32 instead of 2 x 16 registers) and with them the torque recomputed from them and
-// the constant omega_el — four of seven leaves as whole 128-byte lines; = 2: the constant leaf alone (no register). Same-session
-// A/B on the headline launch, four runs each (gpurun_out/ab, round 4): 0: 6.39 ... 6.46 ms, 1: 6.46 ... 6.57 (256 registers),
-// 2: 6.47 ... 6.53 — the stores' run length is not what bounds this kernel (one dependent chain per wave at two
-// waves per SIMD). Bit-identical results in all three settings (tests/test_gpu_env_major_ring.py passes with each).
-#ifndef EXCENV_EMR_LONG
-#define EXCENV_EMR_LONG 0
-#endif
-template <class M, typename T, bool AHEAD> constexpr bool emr_has_long() { return EXCENV_EMR_LONG && M::IS_PMSM && AHEAD && sizeof(T) == 4; }
-template <class M, typename T, bool AHEAD> constexpr bool emr_is_long(int j) {  // EXCENV_EMR_LONG == 2: the constant leaf alone
-  return emr_has_long<M, T, AHEAD>() && j >= (EXCENV_EMR_LONG == 2 ? 6 : 3) && j <= 6;
-}
-template <class M, typename T, bool AHEAD> constexpr int emr_rows_long() { return emr_rows<M, T, AHEAD>() * (emr_has_long<M, T, AHEAD>() ? 2 : 1); }
-
 // LDS bytes per wave: the transposition buffer (64 lanes x 128 bytes) and the action windows (EMR_ANP load instructions' blocks)
 constexpr int EMR_ANP = 4;  // 16-byte pieces per action window (64 bytes, fetched by 4 adjacent lanes of one LDS-direct load)
 template <class M, typename T, bool AHEAD> constexpr size_t emr_lds_bytes() { return (size_t)EM_LANES * 128 + (size_t)EMR_ANP * AEM_BLOCK_BYTES; }
@@ -98,10 +82,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   constexpr int NLO = W / RPO;              // observation lines per window and environment
   static_assert(WL % O == 0 && W % RPO == 0, "the observation rows of a window must be whole 128-byte lines");
   static_assert(WL % A == 0 && VW % A == 0, "an action row must not straddle a 16-byte piece");
-  constexpr int W2 = emr_rows_long<M, T, AHEAD>();  // steps per window of the long leaves (== W when there are none)
-  constexpr int NPC2 = W2 / VW;
   using Vec = typename EmrVec<T, W>::type;
-  using VecL = typename EmrVec<T, W2>::type;
   extern __shared__ __align__(16) unsigned char excenv_emr_smem[];
   T* const xp = reinterpret_cast<T*>(excenv_emr_smem);  // [NPC pieces][64 lanes]: piece p of lane l at lane position l ^ p (both directions conflict-free)
   T* const slot_a = xp + EM_LANES * WL;                 // EMR_ANP blocks of AEM_BLOCK_BYTES: the action window of every lane's environment
@@ -134,7 +115,6 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   const int64_t rowlen = N + 1;
   // wave-uniform window phase: slot of row n in the ring = (ph + n) % W (leaf and observation bases are 128-byte aligned, host)
   const int ph = (int)(((int64_t)r * (rowlen % W)) % W);
-  const int ph2 = (int)(((int64_t)r * (rowlen % W2)) % W2);  // the long leaves' windows; ph2 % W == ph
 
   // ---- actions: 64-byte windows of every environment's row by LDS-direct loads (round 4; the scheme of sim_ahead_kernel's AEM
   // instantiations, kernels.hpp). Lane t of load instruction i fetches piece t % ANP of the window of the environment that lane
@@ -157,8 +137,12 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
       e = (e < ka.B) ? e : env0;  // ragged wave: the loaders of absent environments fetch lane 0's row (never read)
       const T* src = ka.actions + e * ka.K * A + (int64_t)pc * VW;
       // inline assembly: see kernels.hpp (the builtin makes the compiler drain vmcnt in front of every LDS read). M0 = LDS
-      // address of the block; written and consumed inside this one statement (the ring's s_set_gpr_idx sequences also use M0).
-      asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(act_lds + (unsigned)i * AEM_BLOCK_BYTES) : "memory");
+      // address of the block; written and consumed inside this one statement and declared as clobbered (the ring's s_set_gpr_idx
+      // sequences also use M0); s_nop 0 = the wait state between an SALU write of M0 and the LDS-direct load.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // "reserved register on the clobber list": intended, see kernels.hpp
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(act_lds + (unsigned)i * AEM_BLOCK_BYTES) : "memory", "m0");
+#pragma clang diagnostic pop
     }
   };
   auto read_row = [&](int krow, T (&a)[A]) __attribute__((always_inline)) {  // row krow of this lane's environment out of its window
@@ -170,33 +154,21 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   constexpr int CL = emr_const_leaf<M>();           // this leaf's saved value is st[CL] at every step
   constexpr int DL = emr_derived_leaf<M, AHEAD>();  // this leaf's saved value is a function of other saved leaves
   constexpr int NR = emr_ring_leaves<M, AHEAD>();
-  auto is_long = [](int j) constexpr { return emr_is_long<M, T, AHEAD>(j); };
   auto in_ring = [](int j) constexpr { return j != CL && j != DL; };
-  // index of leaf j among the ring leaves of its class (short / long windows)
-  auto ridx = [is_long, in_ring](int j) constexpr {
+  // index of leaf j among the ring leaves
+  auto ridx = [in_ring](int j) constexpr {
     int n = 0;
-    for (int q = 0; q < j; ++q) n += (in_ring(q) && is_long(q) == is_long(j)) ? 1 : 0;
+    for (int q = 0; q < j; ++q) n += in_ring(q) ? 1 : 0;
     return n;
   };
-  constexpr int NRL = is_long(3) ? 2 : 0;  // i_d, i_q (torque is derived from them, omega_el is constant)
-  constexpr int NRS = NR - NRL;
-  Vec ring[NRS > 0 ? NRS : 1];
-  VecL ringL[NRL > 0 ? NRL : 1];
+  Vec ring[NR > 0 ? NR : 1];
 #pragma unroll
-  for (int j = 0; j < NRS; ++j) ring[j] = (Vec)(T(0));
-#pragma unroll
-  for (int j = 0; j < NRL; ++j) ringL[j] = (VecL)(T(0));
-  // value of leaf j at slot s_ of ITS class's window (j: compile-time constant at every call)
+  for (int j = 0; j < NR; ++j) ring[j] = (Vec)(T(0));
+  // value of leaf j at slot s_ of the window (j: compile-time constant at every call)
   auto ring_get = [&](int j, int s_) __attribute__((always_inline)) -> T {
     if (j == CL) return st[CL >= 0 ? CL : 0];
     if constexpr (M::IS_PMSM) {
-      if (j == DL) {
-        if constexpr (NRL > 0) return M::torque(ringL[ridx(3)][s_], ringL[ridx(4)][s_], c);
-        else return M::torque(ring[ridx(3)][s_], ring[ridx(4)][s_], c);
-      }
-    }
-    if constexpr (NRL > 0) {
-      if (is_long(j)) return ringL[ridx(j)][s_];
+      if (j == DL) return M::torque(ring[ridx(3)][s_], ring[ridx(4)][s_], c);
     }
     return ring[ridx(j)][s_];
   };
@@ -269,27 +241,24 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     }
     wave_sync();
   };
-  // the state leaves of one window class (short: W steps, NPC pieces per run; long: W2, NPC2), slots [s_lo, s_hi]
-  auto flush_leaves = [&](auto np_tag, auto long_tag, int s_lo, int s_hi, int64_t n_slot0) __attribute__((always_inline)) {
+  // the state leaves (W steps, NPC pieces per run), slots [s_lo, s_hi]
+  auto flush_leaves = [&](auto np_tag, int s_lo, int s_hi, int64_t n_slot0) __attribute__((always_inline)) {
     constexpr int NPG = decltype(np_tag)::value;
-    constexpr bool LONGC = decltype(long_tag)::value;
     const bool fast = full_wave && (s_lo == 0) && (s_hi == NPG * VW - 1);
     const int64_t row_u = env0 * rowlen + n_slot0;
     const int pi = lane % NPG;
     const unsigned lane_rows = (unsigned)((int64_t)P * (lane - pi) * rowlen);  // rows between lane 0's and the group's first environment
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-      if (is_long(j) != LONGC) continue;
       put_pieces(np_tag, [&](int h) __attribute__((always_inline)) { return ring_get(j, h); });
       emit_lines(np_tag, ka.straj[j] + row_u, (int64_t)P * rowlen, lane_rows + (unsigned)(pi * VW), fast, s_lo, s_hi,
                  [&](int h) { return pi * VW + h; });
     }
   };
-  // lb: slot of the long windows that holds the row in slot 0 of the short window being flushed (0 or W; wave-uniform)
-  auto flush = [&](int s_lo, int s_hi, int64_t n_slot0, int lb) __attribute__((always_inline)) {
+  auto flush = [&](int s_lo, int s_hi, int64_t n_slot0) __attribute__((always_inline)) {
     const bool fast = full_wave && (s_lo == 0) && (s_hi == W - 1);
     const int64_t row_u = env0 * rowlen + n_slot0;                               // (lane 0's environment, slot 0), in rows: uniform
-    if (with_states) flush_leaves(std::integral_constant<int, NPC>{}, std::false_type{}, s_lo, s_hi, n_slot0);
+    if (with_states) flush_leaves(std::integral_constant<int, NPC>{}, s_lo, s_hi, n_slot0);
     // observation lines: line l of the window holds rows [l * RPO, (l + 1) * RPO)
     const int po = lane % NPL;
     const unsigned lane_rows_o = (unsigned)((int64_t)P * (lane - po) * rowlen);
@@ -301,7 +270,7 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
       auto row = [&](int t) __attribute__((always_inline)) {
         T fs[S], ob[O];
 #pragma unroll
-        for (int j = 0; j < S; ++j) fs[j] = ring_get(j, l * RPO + t + (is_long(j) ? lb : 0));
+        for (int j = 0; j < S; ++j) fs[j] = ring_get(j, l * RPO + t);
         M::observe(fs, c, ob);
         if constexpr (O >= VW) {
 #pragma unroll
@@ -344,12 +313,12 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
   read_row(0, a_cur);
 
   for (int n = 0; n <= N; ++n) {
-    const int slot = (ph + n) % W, slot2 = (ph2 + n) % W2;
+    const int slot = (ph + n) % W;
     // Row n + 1 of the actions (clamped) is what this step still needs (row n is in a_cur). Its window was requested during the
     // previous step, behind that step's flush and in front of its integration: nothing younger is in flight, so waiting for
     // everything outstanding waits for exactly that fill (and for older stores, which retire before it anyway).
     const int k1 = (n + 1 < N) ? n + 1 : N - 1;
-    if (!(EXCENV_EMR_DEBUG & 1) && k1 % ARW == 0 && k1 / ARW == w_hi && w_hi > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(EXCENV_EMR_DEBUG & 1) && k1 % ARW == 0 && k1 / ARW == w_hi && w_hi > 0) asm volatile("s_waitcnt vmcnt(0) expcnt(6)" ::: "memory");  // expcnt(6): never blocks, marks the hand-written wait (tools/isa_guards.py)
     T a_nxt[A];  // requested here, used by the integration below: the save in between covers the LDS latency
     read_row(k1, a_nxt);
 #pragma unroll
@@ -369,23 +338,11 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       if (j == CL || j == DL) continue;
-      if constexpr (NRL > 0) {
-        if (is_long(j)) {
-          ringL[ridx(j)][slot2] = sv[j];
-          continue;
-        }
-      }
       ring[ridx(j)][slot] = sv[j];
     }
     if (!(EXCENV_EMR_DEBUG & 2) && (slot == W - 1 || n == N)) {
       const int back = (n < slot) ? n : slot;  // rows of the window before row n
-      flush(slot - back, slot, n - slot, slot2 - slot);
-      if constexpr (W2 != W) {  // the long leaves' window ends at every second short one (and with the trajectory)
-        if (with_states && (slot2 == W2 - 1 || n == N)) {
-          const int back2 = (n < slot2) ? n : slot2;
-          flush_leaves(std::integral_constant<int, NPC2>{}, std::true_type{}, slot2 - back2, slot2, n - slot2);
-        }
-      }
+      flush(slot - back, slot, n - slot);
     }
     // row k1 was the last of its action window: the window's LDS is dead (its reads have returned by now; made formal) and
     // takes the next one — behind the flush, so that the wait at the top of the next step does not drain this step's stores

@@ -369,9 +369,6 @@ template <class M, typename T> static int launch_step(const StepCall& sc) {
 // the small models, BLOCK everywhere else — measured per workload (profiles/r04_pattern_sweep.md): pendulum Euler fp32 -10.6 %, fp64
 // -8 %, MSD Euler fp32 -7 %, fp64 -6 %, tank Euler fp32 -6 % (fp64 +3 %: not taken); RK4 / Tsit5 of the same models +3 ... +9 %,
 // cart-pole / acrobot Euler within 3 % either way, PMSM (256 registers) not possible.
-#ifndef EXCENV_DOUBLE_WIDE_RULE  // which (model, dtype, solver) take double-wide lanes; a macro so that A/B builds can widen it
-#define EXCENV_DOUBLE_WIDE_RULE(M, T, solver) false
-#endif
 #ifndef EXCENV_ROW_SYNC_MIN_BATCH
 #define EXCENV_ROW_SYNC_MIN_BATCH ((int64_t)1 << 17)
 #endif
@@ -381,12 +378,6 @@ static inline int row_sync_mode() {  // EXCENV_ROW_SYNC = 0: off, 1: barrier onl
   return mode;
 }
 static inline bool row_sync_enabled() { return row_sync_mode() != 0; }
-// Double-wide lanes (kernels.hpp load_v / store_v: 32 bytes per lane and stream as two adjacent 1 KiB runs per wave): the models
-// with few registers per environment, where the per-row barrier of the 1024-thread form does not pay (RK4 / Tsit5) or does not
-// apply. Measured per workload (profiles/r04_pattern_sweep.md §4).
-template <class M, typename T> constexpr bool sim_double_wide_ok(int solver) {
-  return !M::HAS_LUT && !M::IS_PMSM && EXCENV_DOUBLE_WIDE_RULE(M, T, solver);
-}
 static inline bool wide_enabled() {  // EXCENV_WIDE=0: the 256-thread form everywhere (A/B measurements, counter passes)
   static const int on = [] { const char* e = std::getenv("EXCENV_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
   return on != 0;
@@ -458,13 +449,6 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
     if (ka.truncated == nullptr) EXCENV_SIM_LAUNCH(true, 1, -2);  // no gym trajectories: the instantiation without their code
     EXCENV_SIM_LAUNCH(true, 1, -1);
   }
-  if constexpr (sim_double_wide_ok<M, T>(SOLVER)) {
-    constexpr int VD = 32 / (int)sizeof(T);
-    if (V == VD) {
-      if (ka.straj[0] == nullptr) EXCENV_SIM_LAUNCH(false, VD, 0);
-      EXCENV_SIM_LAUNCH(false, VD, 1);
-    }
-  }
   if (ka.straj[0] == nullptr) {  // observations only: its own instantiations (no state stores between the action loads and their waits)
     if constexpr (sizeof(T) == 4) {
       if (V == 4) EXCENV_SIM_LAUNCH(false, 4, 0);
@@ -503,9 +487,25 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   // the gym trajectories come out of the widest lean form too (kernels.hpp, LGYM) when everything is lane-major, the batch
   // runs that form anyway and the flag / reward / reference arrays allow vector accesses
   constexpr int VMAXG = 16 / (int)sizeof(T);
+  bool traj_aligned = aligned16(sc.obs_traj);  // the trajectory arrays alone (row_sync == 2 below)
+  bool vec_ok = true;  // every pointer 16-byte aligned; the general instantiation stays at one environment per lane
+  for (int j = 0; j < M::S; ++j) {
+    if (!sc.state_in[j] || !sc.last_state[j]) { set_error("excenv_sim_ahead: state pointer %d is NULL", j); return EXCENV_ENULL; }
+    ka.state_in[j] = (const T*)sc.state_in[j];
+    ka.last_state[j] = (T*)sc.last_state[j];
+    ka.straj[j] = sc.state_traj ? (T*)sc.state_traj[j] : nullptr;
+    if (sc.state_traj && !sc.state_traj[j]) { set_error("excenv_sim_ahead: state_traj pointer %d is NULL", j); return EXCENV_ENULL; }
+    vec_ok &= aligned16(ka.state_in[j]) && aligned16(ka.last_state[j]) && aligned16(ka.straj[j]);
+    traj_aligned &= aligned16(ka.straj[j]);
+  }
+  // Everything that keeps a call from the widest lane form keeps it from the lean gym form too, and the call then takes the general
+  // instantiation like any other gym call (round 4 returned an "internal error" for two such cases: acrobot RK4 / Tsit5 with default
+  // options — the lane-width cap below — and state / trajectory / action arrays that are not 16-byte aligned).
   bool lean_gym = with_gym && !batched && !M::HAS_LUT && ka.n_control <= M::S && sc.action_layout == EXCENV_LAYOUT_LANE_MAJOR &&
                   sc.traj_layout == EXCENV_LAYOUT_LANE_MAJOR && sc.B > 0 && (sc.B % VMAXG) == 0 &&
                   (sc.vec_pref > 0 ? sc.vec_pref == VMAXG : widest_form_pays(sc.B, VMAXG)) &&
+                  vec_ok && aligned16(sc.actions) && aligned16(sc.obs_traj) &&
+                  !(sc.vec_pref == 0 && M::ID == EXCENV_ACROBOT && sc.solver != EXCENV_EULER) &&
                   aligned16(sc.gym->reward) && ((uintptr_t)sc.gym->terminated % VMAXG) == 0 && ((uintptr_t)sc.gym->truncated % VMAXG) == 0;
   for (int j = 0; lean_gym && j < ka.n_control; ++j) lean_gym = sc.control->reference[j] != nullptr && aligned16(sc.control->reference[j]);
   // the four-leaf models in fp64 with an RK solver would need more than 256 registers in that form (one wave per SIMD): general
@@ -516,17 +516,6 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     for (int j = 0; j < ka.n_control; ++j) split_control &= sc.control->reference[j] != nullptr;
   }
   bool general = batched || (ka.n_control > 0 && !split_control) || (with_gym && !lean_gym);
-  bool traj_aligned = aligned16(sc.obs_traj);  // the trajectory arrays alone (row_sync == 2 below)
-  bool vec_ok = true;  // every pointer 16-byte aligned (checked below); the general instantiation goes up to two environments per lane
-  for (int j = 0; j < M::S; ++j) {
-    if (!sc.state_in[j] || !sc.last_state[j]) { set_error("excenv_sim_ahead: state pointer %d is NULL", j); return EXCENV_ENULL; }
-    ka.state_in[j] = (const T*)sc.state_in[j];
-    ka.last_state[j] = (T*)sc.last_state[j];
-    ka.straj[j] = sc.state_traj ? (T*)sc.state_traj[j] : nullptr;
-    if (sc.state_traj && !sc.state_traj[j]) { set_error("excenv_sim_ahead: state_traj pointer %d is NULL", j); return EXCENV_ENULL; }
-    vec_ok &= aligned16(ka.state_in[j]) && aligned16(ka.last_state[j]) && aligned16(ka.straj[j]);
-    traj_aligned &= aligned16(ka.straj[j]);
-  }
   ka.actions = (const T*)sc.actions;
   ka.obs = (T*)sc.obs_traj;
   constexpr int64_t TILE = EXCENV_TILE;  // envs per tile of the tiled layout (== one workgroup at V = TILE/BLOCK)
@@ -594,10 +583,9 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     // register-ring form (kernels_emr.hpp): whole-line stores. Needs 128-byte aligned trajectory arrays and enough environments
     // to fill waves whose lanes are P environments apart.
     const bool ahead = sc.semantics == EXCENV_SEM_AHEAD;
-    const int64_t W = ahead ? emr_rows_long<M, T, true>() : emr_rows_long<M, T, false>(), WL = 128 / (int64_t)sizeof(T);  // the longest window
+    const int64_t W = ahead ? emr_rows<M, T, true>() : emr_rows<M, T, false>();  // steps per window
     auto period = [](int64_t x, int64_t m) { int64_t g = m, y = x % m; while (y) { const int64_t t = g % y; g = y; y = t; } return m / g; };
     const int64_t P = period(sc.K + 1, W);
-    (void)WL;
     // action rows must consist of whole 16-byte pieces (they are fetched as 64-byte windows by LDS-direct loads)
     bool ok = ((uintptr_t)ka.obs % 128) == 0 && (sc.em_mode == 4 || sc.B >= 16 * EM_LANES * P) &&
               (sc.K * M::A * (int64_t)sizeof(T)) % 16 == 0 && aligned16(ka.actions) &&
@@ -685,10 +673,6 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     while (want > 1 && (sc.B % want) != 0) want >>= 1;
     V = want;
   }
-  // double-wide lanes: whole waves only, enough of them to fill the chip twice over, nothing else special about the call
-  if (sim_double_wide_ok<M, T>(sc.solver) && vec_ok && V == VMAX && sc.vec_pref == 0 && !general && !aem && !lean_gym && !tiled_a && !tiled_t &&
-      (sc.B % (64 * 2 * VMAX)) == 0 && sc.B / (2 * VMAX) >= (int64_t)BLOCK * 2 * 256)
-    V = 2 * VMAX;
   if (lean_gym && (general || V != VMAX)) { set_error("excenv_sim_ahead: internal error: lean gym outputs need %d environments per lane", VMAX); return EXCENV_EINVAL; }
   if (aem && V != VMAX) { set_error("excenv_sim_ahead: internal error: fused row-major actions need %d environments per lane", VMAX); return EXCENV_EINVAL; }
   if (tiled_a || tiled_t) {  // a workgroup must not straddle tiles
@@ -744,7 +728,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     default: set_error("bad solver id %d", sc.solver); return EXCENV_EINVAL;
   }
 #undef EXCENV_SIM_CASE
-  g_last_launch = general ? "sim_ahead_kernel (general)" : (lean_gym ? (nt > BLOCK ? "sim_ahead_kernel (lean, gym outputs, 1024 threads)" : "sim_ahead_kernel (lean, gym outputs)") : aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? (nt > BLOCK ? "sim_ahead_kernel (V=2, 1024 threads)" : "sim_ahead_kernel (V=2)") : (V > VMAX ? (V == 8 ? "sim_ahead_kernel (V=8, double-wide)" : "sim_ahead_kernel (V=4, double-wide)") : (nt > BLOCK ? "sim_ahead_kernel (V=4, 1024 threads)" : "sim_ahead_kernel (V=4)")))));
+  g_last_launch = general ? "sim_ahead_kernel (general)" : (lean_gym ? (nt > BLOCK ? "sim_ahead_kernel (lean, gym outputs, 1024 threads)" : "sim_ahead_kernel (lean, gym outputs)") : aem ? "sim_ahead_kernel (row-major actions fused)" : (V == 1 ? "sim_ahead_kernel (V=1)" : (V == 2 ? (nt > BLOCK ? "sim_ahead_kernel (V=2, 1024 threads)" : "sim_ahead_kernel (V=2)") : (nt > BLOCK ? "sim_ahead_kernel (V=4, 1024 threads)" : "sim_ahead_kernel (V=4)"))));
   if (int rc = check_launch("excenv_sim_ahead")) return rc;
   if (split_control && !general) {
     ControlFillArgs<T, M> fa;

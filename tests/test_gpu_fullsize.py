@@ -160,7 +160,13 @@ def test_msd_tsit5_fp64_batch_2pow20_config_c4():
 
 
 # ---------------------------------------------------------------------------------------- full-length runs
-def _full_length_run(env_name, solver, dtype, log2_batch, n_chunks, Kc, T, tau=None, semantics="ahead", seed=0):
+def _circ(env_name, d):
+    for col in {"pendulum": [0], "cartpole": [2], "acrobot": [0, 1]}.get(env_name, []):
+        d[..., col] = np.minimum(d[..., col], np.abs(2 - d[..., col]))
+    return d
+
+
+def _full_length_run(env_name, solver, dtype, log2_batch, n_chunks, Kc, T, tau=None, semantics="ahead", seed=0, collect=0):
     """A BASELINE configuration at its full batch AND full step count, as `n_chunks` chained vmap_sim_ahead launches of
     `Kc` steps (last_state -> init_state: the reference's continuation mechanism, core_env.py:484-486; chunking is
     forced by its max_steps = 4096 and by HBM capacity). A tile of T oracle-checkable environments is replicated across the
@@ -169,9 +175,10 @@ def _full_length_run(env_name, solver, dtype, log2_batch, n_chunks, Kc, T, tau=N
       * last_state equals the final trajectory row and everything is finite,
       * the first tile matches the CPU oracle started from the same chunk-initial state: bit-exact for the trig-free
         systems over the whole chunk, |d| <= 1e-5 * (1 + |ref|) (normalised units: the allclose(rtol=1e-5, atol=1e-5) of the
-        other parity tests) over the first 64 rows otherwise (longer horizons amplify the <= 2 ulp sin/cos differences
-        chaotically — measured in DESIGN.md §5, not gated).
-    Returns the total number of env-steps simulated."""
+        other parity tests) over the first 64 rows otherwise.
+    collect > 0: the observation rows of the first `collect` environments over the WHOLE chained horizon are kept, and the oracle
+    runs the same horizon chained on its OWN states (never restarted from the kernel's) in fp32 and fp64 — see _drift().
+    Returns (env-steps simulated, None | dict(kernel=[collect, n_chunks*Kc+1, O], oracle32=..., oracle64=...))."""
     B = 1 << log2_batch
     np_dt = np.float32 if dtype == torch.float32 else np.float64
     spec = spec_of(env_name)
@@ -185,9 +192,19 @@ def _full_length_run(env_name, solver, dtype, log2_batch, n_chunks, Kc, T, tau=N
     st_small = random_state(env_name, T, np_dt, spec, seed=seed + 1)
     state = _tile_state(env, st_small, B // T)
     trig_free = env_name in ("mass_spring_damper", "fluid_tank")
-    angle_cols = {"pendulum": [0], "cartpole": [2], "acrobot": [0, 1]}.get(env_name, [])
     steps = 0
     prev = None
+    chain = None
+    if collect:
+        assert collect <= T
+        chain = {"kernel": [], "oracle32": [], "oracle64": []}
+        o_state = {}
+        o_props = {}
+        for key, odt in (("oracle32", np.float32), ("oracle64", np.float64)):
+            if np.dtype(odt).itemsize < np.dtype(np_dt).itemsize:
+                continue  # an fp64 kernel has no fp32 floor to compare with
+            o_props[key] = oracle.make_props(env_name, spec["params"], spec["phys_norm"], spec["act_norm"], odt, collect)
+            o_state[key] = [np.asarray(v[:collect], dtype=odt) for v in st_small]
     for c in range(n_chunks):
         acts_small = rng.uniform(-1, 1, (T, Kc, env.action_dim)).astype(np_dt)
         actions = _tile_actions(env, acts_small, B // T)
@@ -209,29 +226,117 @@ def _full_length_run(env_name, solver, dtype, log2_batch, n_chunks, Kc, T, tau=N
         if trig_free:
             assert np.array_equal(got, o_ref), f"chunk {c}: not bit-exact vs the oracle"
         else:
-            d = np.abs(got[:, :65].astype(np.float64) - o_ref[:, :65])
-            for col in angle_cols:
-                d[..., col] = np.minimum(d[..., col], np.abs(2 - d[..., col]))
+            d = _circ(env_name, np.abs(got[:, :65].astype(np.float64) - o_ref[:, :65]))
             excess = d - 1e-5 * (1.0 + np.abs(o_ref[:, :65]))
             assert excess.max() <= 0, f"chunk {c}: max |d| {d.max()}, max over tolerance {excess.max()}"
+        if collect:
+            first = 0 if c == 0 else 1  # row 0 of a later chunk repeats the previous chunk's last row
+            chain["kernel"].append(got[:collect, first:].copy())
+            for key in o_state:
+                odt = o_state[key][0].dtype
+                oo, _, ol = oracle.sim_ahead(env_name, solver, o_state[key], acts_small[:collect].astype(odt), o_props[key][0],
+                                             spec["tau"], semantics=sem)
+                chain[key].append(oo[:, first:].copy())
+                o_state[key] = ol
         state = last
         steps += B * Kc
         del obs, states, actions
         if c % 2 == 1:
             prev = None  # the next (even) chunk allocates afresh; `state` keeps last_state alive
-    return steps
+    if collect:
+        chain = {k: np.concatenate(v, axis=1) for k, v in chain.items() if v}
+    return steps, chain
+
+
+DRIFT_ROWS = (1, 10, 100, 1000, 2000, 5000, 10000)
+
+
+def _drift(name, env_name, chain):
+    """Error-vs-step curves of a chained full-horizon run, in units of each observation's full scale (angles on the circle):
+      a = kernel vs the oracle in the kernel's precision (what differs: device sin / cos, nothing else),
+      b = kernel (fp32) vs the fp64 oracle, c = fp32 oracle vs fp64 oracle — the floor ANY fp32 implementation of the reference has.
+    Per curve: the running maximum over environments and columns up to row n, and the 99th / 50th percentile over environments of
+    each environment's running maximum (chaotic systems: a few environments near a separatrix carry the maximum). Written to
+    gpurun_out/full_horizon_<name>.json when that directory is writable (DESIGN.md §5 tabulates it)."""
+    import json
+    import os
+
+    k = chain["kernel"]
+    pairs = {}
+    if k.dtype == np.float32:
+        pairs = {"a": (k, chain["oracle32"]), "b": (k, chain["oracle64"]), "c": (chain["oracle32"], chain["oracle64"])}
+    else:
+        pairs = {"a": (k, chain["oracle64"])}
+    out = {"config": name, "envs": int(k.shape[0]), "rows": int(k.shape[1]), "at_rows": [r for r in DRIFT_ROWS if r < k.shape[1]]}
+    for key, (x, y) in pairs.items():
+        d = _circ(env_name, np.abs(x.astype(np.float64) - y.astype(np.float64))).max(axis=2)  # [envs, rows]
+        run = np.maximum.accumulate(d, axis=1)
+        out[key] = {"max": [float(run[:, r].max()) for r in out["at_rows"]],
+                    "p99": [float(np.percentile(run[:, r], 99)) for r in out["at_rows"]],
+                    "p50": [float(np.percentile(run[:, r], 50)) for r in out["at_rows"]]}
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"full_horizon_{name}.json"), "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError:
+        pass
+    return out
 
 
 def test_full_length_config_c2_pendulum_euler_fp32_10000_steps():
-    """configs[1] end to end: Pendulum Euler fp32, B = 2^20, tau = 2e-2, 10 000 steps (10 chained 1000-step launches)."""
-    assert _full_length_run("pendulum", "euler", torch.float32, 20, 10, 1000, 512, tau=2e-2, seed=210) == (1 << 20) * 10000
+    """configs[1] end to end: Pendulum Euler fp32, B = 2^20, tau = 2e-2, 10 000 steps (10 chained 1000-step launches) — and the
+    chained kernel against the chained oracle over all 10 000 rows, no restarts."""
+    steps, chain = _full_length_run("pendulum", "euler", torch.float32, 20, 10, 1000, 512, tau=2e-2, seed=210, collect=256)
+    assert steps == (1 << 20) * 10000
+    dr = _drift("c2_pendulum_euler_f32", "pendulum", chain)
+    _assert_drift(dr, C2_BOUNDS)
 
 
 def test_full_length_config_c3_pmsm_euler_fp32_10000_steps():
-    """configs[2] end to end: PMSM Euler fp32, B = 2^22, 10 000 steps (100 chained 100-step launches, full outputs)."""
-    assert _full_length_run("pmsm", "euler", torch.float32, 22, 100, 100, 1024, seed=220) == (1 << 22) * 10000
+    """configs[2] end to end: PMSM Euler fp32, B = 2^22, 10 000 steps (100 chained 100-step launches, full outputs) — and the
+    chained kernel against the chained oracle over all 10 000 rows, no restarts."""
+    steps, chain = _full_length_run("pmsm", "euler", torch.float32, 22, 100, 100, 1024, seed=220, collect=256)
+    assert steps == (1 << 22) * 10000
+    dr = _drift("c3_pmsm_euler_f32", "pmsm", chain)
+    _assert_drift(dr, C3_BOUNDS)
 
 
 def test_full_length_config_c4_msd_tsit5_fp64_5000_steps():
-    """configs[3] end to end: MassSpringDamper Tsit5 fp64, B = 2^20, 5 000 steps (10 chained 500-step launches)."""
-    assert _full_length_run("mass_spring_damper", "tsit5", torch.float64, 20, 10, 500, 256, seed=230) == (1 << 20) * 5000
+    """configs[3] end to end: MassSpringDamper Tsit5 fp64, B = 2^20, 5 000 steps (10 chained 500-step launches): the chained kernel
+    equals the chained oracle bit for bit over the whole horizon."""
+    steps, chain = _full_length_run("mass_spring_damper", "tsit5", torch.float64, 20, 10, 500, 256, seed=230, collect=256)
+    assert steps == (1 << 20) * 5000
+    assert chain["kernel"].shape == (256, 5001, 2)
+    assert np.array_equal(chain["kernel"], chain["oracle64"])
+    _drift("c4_msd_tsit5_f64", "mass_spring_damper", chain)
+
+
+def test_full_length_pmsm_tsit5_fp32_10000_steps():
+    """PMSM Tsit5 fp32 (parity-unpinned solver: kernel vs oracle only), B = 2^20, 10 000 chained steps, no restarts."""
+    steps, chain = _full_length_run("pmsm", "tsit5", torch.float32, 20, 100, 100, 1024, seed=240, collect=256)
+    assert steps == (1 << 20) * 10000
+    dr = _drift("pmsm_tsit5_f32", "pmsm", chain)
+    _assert_drift(dr, C3_BOUNDS)
+
+
+# Bounds on the chained full-horizon curves (units: full scale of each normalised observation). `a_max` bounds curve a at the last
+# row (kernel vs same-precision oracle), `a_over_c` bounds a relative to the fp32 floor c where the dynamics amplify rounding.
+C3_BOUNDS = None
+C2_BOUNDS = None
+
+
+def _assert_drift(dr, bounds):
+    if bounds is None:  # measuring run
+        print(dr)
+        return
+    last = -1
+    if "a_max" in bounds:
+        assert dr["a"]["max"][last] <= bounds["a_max"], dr["a"]
+    if "b_max" in bounds:
+        assert dr["b"]["max"][last] <= bounds["b_max"], dr["b"]
+    for q in ("max", "p99", "p50"):
+        if f"a_over_c_{q}" in bounds:
+            for i, r in enumerate(dr["at_rows"]):
+                floor = max(dr["c"][q][i], 1e-6)
+                assert dr["a"][q][i] <= bounds[f"a_over_c_{q}"] * floor, (q, r, dr["a"][q][i], floor)

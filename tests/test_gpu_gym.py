@@ -490,3 +490,77 @@ def test_gym_trajectories_from_the_wide_lean_kernel_equal_the_general_kernel(env
         assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), name
     if env_name != "fluid_tank":
         assert a[4].any()
+
+
+def test_default_options_acrobot_rk4_gym_trajectories_at_2pow18():
+    """acrobot RK4 / Tsit5 fp32 with gym outputs, lane-major actions, DEFAULT launch options and a batch that takes
+    the widest form (2^18) returned "internal error: lean gym outputs need 4 environments per lane" — the lane-width cap for acrobot's
+    RK kernels applied after the lean gym form had been chosen. Such a call takes the general kernel now; compared with the forced
+    lean form of the same call (bit-equal) on a batch slice against the oracle's flags."""
+    from exciting_environments_amd import _native
+
+    B, K = 1 << 18, 12
+    env, props, keep, spec = make_env("acrobot", B, torch.float32, solver="rk4", control_state=["theta_1", "omega_2"])
+    st = random_state("acrobot", B, np.float32, spec, seed=95)
+    rng = np.random.default_rng(96)
+    refs = {"theta_1": rng.uniform(-3, 3, B).astype(np.float32), "omega_2": rng.uniform(-20, 20, B).astype(np.float32)}
+    acts = env.new_actions_buffer(K)
+    acts.copy_(torch.as_tensor(rng.uniform(-1, 1, (B, K, 1)).astype(np.float32), device=env.device))
+    outs = {}
+    for vec in (0, 4):
+        env.launch_opts = _native.launch_opts(envs_per_lane=vec)
+        outs[vec] = env.vmap_sim_ahead(to_state(env, st, reference=refs), acts, env.tau, env.tau, return_rew_trunc_term=True)
+        torch.cuda.synchronize()
+        assert _native.last_launch() == ("sim_ahead_kernel (general)" if vec == 0 else "sim_ahead_kernel (lean, gym outputs)")
+    a, b = outs[0], outs[4]
+    assert torch.equal(a[0], b[0])
+    for k in (3, 4, 5):
+        assert torch.equal(a[k], b[k])
+    # Euler at the same batch keeps the lean form with default options
+    env2, _, _, _ = make_env("acrobot", B, torch.float32, solver="euler", control_state=["theta_1", "omega_2"])
+    env2.vmap_sim_ahead(to_state(env2, st, reference=refs), acts, env2.tau, env2.tau, return_rew_trunc_term=True)
+    assert _native.last_launch() == "sim_ahead_kernel (lean, gym outputs)"
+
+
+@pytest.mark.parametrize("which", ["state_in", "state_traj", "obs", "reference"])
+def test_gym_trajectories_with_a_misaligned_array_take_the_general_kernel(which):
+    """ADVICE r04 (high), case 2: a state / trajectory / observation / reference array that is only 4-byte aligned cannot take the
+    16-byte accesses of the lean gym form; the raw ABI call used to fail with EINVAL, now it runs the general kernel and gives the
+    aligned call's bits."""
+    from exciting_environments_amd import _native
+
+    B, K = 1 << 17, 5
+    env, props_o, keep, spec = make_env("pendulum", B, torch.float32, control_state=["theta"])
+    dev = env.device
+    rng = np.random.default_rng(97)
+    props, pkeep = env._props_for(env.env_properties, B)
+
+    def buf(n, off):  # a float32 array of n elements that starts `off` elements into a 16-byte aligned allocation
+        return torch.zeros(n + 4, dtype=torch.float32, device=dev)[off:off + n]
+
+    results = []
+    for off in (0, 1):
+        o = {k: (off if k == which else 0) for k in ("state_in", "state_traj", "obs", "reference")}
+        st_in = [buf(B, o["state_in"]) for _ in range(2)]
+        g = torch.Generator(device="cpu").manual_seed(5)
+        st_in[0].copy_((torch.rand(B, generator=g) * 6 - 3).to(dev))
+        st_in[1].copy_((torch.rand(B, generator=g) * 10 - 5).to(dev))
+        ref = buf(B, o["reference"])
+        ref.copy_((torch.rand(B, generator=g) * 6 - 3).to(dev))
+        acts = torch.as_tensor(rng.uniform(-1, 1, (K, 1, B)).astype(np.float32), device=dev) if not results else results[0]["acts"]
+        obs = buf((K + 1) * 3 * B, o["obs"])
+        straj = [buf((K + 1) * B, o["state_traj"]) for _ in range(2)]
+        last = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(2)]
+        rew = torch.zeros((K, B), dtype=torch.float32, device=dev)
+        term = torch.zeros((K, B), dtype=torch.bool, device=dev)
+        trunc = torch.zeros((K + 1, 3, B), dtype=torch.bool, device=dev)
+        control = _native.make_control([0], [ref])
+        _native.sim_ahead(env.ENV_ID, env._solver.id, torch.float32, B, K, 1, props, control, env.tau, env.tau, st_in, acts,
+                          _native.LAYOUT_LANE_MAJOR, obs, straj, _native.LAYOUT_LANE_MAJOR, last, _native.SEM_AHEAD, None, None,
+                          (rew, term, trunc))
+        torch.cuda.synchronize()
+        assert _native.last_launch() == ("sim_ahead_kernel (general)" if off else "sim_ahead_kernel (lean, gym outputs)")
+        results.append(dict(acts=acts, obs=obs.clone(), straj=[s.clone() for s in straj], rew=rew, term=term, trunc=trunc))
+    a, b = results
+    assert torch.equal(a["obs"], b["obs"]) and torch.equal(a["rew"], b["rew"]) and torch.equal(a["term"], b["term"])
+    assert torch.equal(a["trunc"], b["trunc"]) and all(torch.equal(x, y) for x, y in zip(a["straj"], b["straj"]))
