@@ -599,10 +599,11 @@ def main():
                 "collective": (gatherer.collective if gatherer is not None else None),
                 "gathered_slice_matches_local": gather_ok,
                 "outputs_finite": finite, "setup_steps": setup_steps, "placement_settle_steps": settle_steps,
-                "pooled_set_steady_ms": [None if t.steady_ms is None else round(t.steady_ms, 4) for t in getattr(env, "_traj_sets", [])],
+                "pooled_set_steady_ms": [None if t.steady_ms is None else round(t.steady_ms, 4) for t in env._placement.sets],
+                "pooled_set_first_launch_ms": [None if t.first_ms is None else round(t.first_ms, 4) for t in env._placement.sets],
                 "output_buffers": (("library-pooled output sets: a set is written again once nothing refers to it (the plain "
                                     "functional API, core_env.py trajectory sets); sets made this run: "
-                                    f"{len(getattr(env, '_traj_sets', []))}" if getattr(env, "trajectory_pool", False)
+                                    f"{len(env._placement.sets)}" if getattr(env, "trajectory_pool", False)
                                     else "fresh allocation per step") if bufs is None else
                                    f"one set written again every step (vmap_sim_ahead(out=...)), chosen during set-up as the fastest "
                                    f"of {len(probe_ms) or 1} placements; probe launch ms per placement (rank 0): "

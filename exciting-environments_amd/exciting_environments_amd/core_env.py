@@ -25,6 +25,8 @@ import torch
 
 from . import _native
 from . import random as _random
+from ._placement import StepSlotPool, TrajectoryPlacement
+from ._trajectory import TrajectoryLaunchMixin
 from .solvers import Euler, _Solver
 from .tree import tree_structure
 
@@ -44,7 +46,7 @@ _cuda_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.curr
 _cuda_is_capturing = getattr(torch._C, "_cuda_isCurrentStreamCapturing", None) or torch.cuda.is_current_stream_capturing
 
 
-class CoreEnvironment(ABC):
+class CoreEnvironment(TrajectoryLaunchMixin, ABC):
     """Core structure of the provided environments (reference core_env.py:15-57).
 
     The simulated systems are physical state-space models dx/dt = f(x(t), u(t)); outputs are
@@ -121,22 +123,12 @@ class CoreEnvironment(ABC):
         self._packed_for = None
         self._flag_cache = {}
         self._obs_dim_cache = None
-        # vmap_step fast path (see _vmap_step_launch): output slots carved from one allocation per `n` calls, pointer arrays
-        # pre-built per slot, and the identity of the state we returned last (its pointer array is the next call's input)
-        self._slots = {False: None, True: None}
-        # large vmap_sim_ahead outputs (see _TrajSet): dead output sets are written again instead of re-allocated, and a new
-        # set is checked for a slow physical placement before its first use. Both are invisible to callers (the functional
-        # contract holds: a set is handed out again only when nothing can observe it); knobs for experiments:
+        # Output memory of the hot path (_placement.py): vmap_step's recycled output slots; the pooled, placed output sets of large
+        # vmap_sim_ahead calls. Both are invisible to callers (a buffer is handed out again only when nothing can observe it).
+        self._step_pool = StepSlotPool(self)
         self.trajectory_pool = True          # False: every large call allocates its outputs (the behaviour up to round 2)
-        self.trajectory_placement = "auto"   # "auto": arena pair, search as fall-back; "search": round 3's search only; "off": none
-        self.last_placement = None           # diagnostics of the most recent placement check (dict) or None
-        self._traj_sets = []
-        self._placement_best = {}
-        self._placement_replaced = {}
-        self._placement_target = None
-        self._arena_made = set()
-        self._fill_gbs = None
-        self._pool_wait_events = []
+        self.trajectory_placement = "auto"   # "auto": ordered pair, search as fall-back; "search": the search only; "off": none
+        self._placement = TrajectoryPlacement(self)
         self._traj_bcast_cache = None
         self._ws_bytes_cache = None
         self._fused_actions_cache = None
@@ -521,104 +513,9 @@ class CoreEnvironment(ABC):
         return obs[0], new_state
 
     # -- vmap_step fast path -------------------------------------------------------------------------------------------
-    # The reference's HOT LOOP #1 is a Python loop of vmap_step calls (README.md:28-32); at RL batch sizes the kernel takes
-    # a few microseconds, so the host side decides the rate. Per call this path does: identity check of the incoming state
-    # leaves (did we return them last time? then their pointer array is already built), one data_ptr() for the action, one
-    # ctypes call with pre-built arguments, two small dataclass constructions. Outputs are still fresh memory every call
-    # (functional contract): slots are carved from one allocation per `n` calls. Once a pool is used up its oldest slot is
-    # handed out again ONLY if nothing outside this object can still see it — no Python reference to any of its tensors or
-    # to its PhysicalState (sys.getrefcount back at the value recorded when the pool was made), no C++ holder of a tensor
-    # (Tensor._use_count() == 1: autograd, DLPack, views keep their base), no foreign view on the pool's storage (storage
-    # use count back at its recorded value) and the same stream as before (the kernels that read the slot are then ordered
-    # before the one that overwrites it). In `obs, state = env.vmap_step(state, act)` the outputs of two calls ago are dead,
-    # so the loop runs on recycled tensor objects: creating the S + 1 views per call was the largest item of the host time.
-    # Anything still referenced makes the test fail and a new pool is allocated, as before.
-    class _Slots:
-        __slots__ = ("n", "i", "leaves", "obs", "out_ptrs", "obs_ptrs", "gym", "gym_ptrs", "phys", "objs", "tens", "rc0",
-                     "storages", "use0", "stream", "obs_width")
-
-    _SPLIT_SLOT_POOL_BYTES = 256 << 20
-    _storage_use_count = getattr(torch._C, "_storage_Use_Count", None)
-    _tensor_use_count = getattr(torch.Tensor, "_use_count", None)
-
-    def _new_slots(self, n: int, gym: bool):
-        B, S, O = self.batch_size, self.physical_state_dim, self._obs_dim()
-        isz = torch.empty((), dtype=self.dtype).element_size()
-        al = 16 // isz
-        Bp = (B + al - 1) // al * al
-        obs_elems = (B * O + al - 1) // al * al
-        rew_elems = Bp if gym else 0
-        slot = S * Bp + obs_elems + rew_elems
-        # Large pools: the observations get their own allocation, so that a caller who keeps only observations (a rollout
-        # buffer) does not pin the state leaves of the pool as well. (Placing the two a region apart, DESIGN.md §6.1, was
-        # measured and does nothing for this short streaming kernel.) Small pools stay one allocation (host time).
-        split = n * slot * isz >= self._SPLIT_SLOT_POOL_BYTES
-        if split:
-            slot -= obs_elems
-        buf = torch.empty(n * slot, dtype=self.dtype, device=self.device)
-        base = buf.data_ptr()
-        sl = CoreEnvironment._Slots()
-        sl.n, sl.i = n, 0
-        sl.leaves = [t.unbind(0) for t in buf.as_strided((n, S, B), (slot, Bp, 1)).unbind(0)]
-        obuf = None
-        if split:
-            obuf = torch.empty(n * obs_elems, dtype=self.dtype, device=self.device)
-            obase = obuf.data_ptr()
-            sl.obs = obuf.as_strided((n, B, O), (obs_elems, O, 1)).unbind(0)
-            sl.obs_ptrs = [obase + i * obs_elems * isz for i in range(n)]
-            obs_elems = 0  # the reward column (gym) follows the leaves directly
-        else:
-            sl.obs = buf.as_strided((n, B, O), (slot, O, 1), S * Bp).unbind(0)
-            sl.obs_ptrs = [base + (i * slot + S * Bp) * isz for i in range(n)]
-        sl.out_ptrs = [_native.ptr_array([base + (i * slot + j * Bp) * isz for j in range(S)]) for i in range(n)]
-        sl.gym = sl.gym_ptrs = None
-        if gym:
-            TW = _native.truncated_width(self.ENV_ID, len(self.control_state))
-            flags = torch.empty((n, B * (1 + TW)), dtype=torch.bool, device=self.device)
-            fbase = flags.data_ptr()
-            rew = buf.as_strided((n, B, 1), (slot, 1, 1), S * Bp + obs_elems).unbind(0)
-            term = flags.as_strided((n, B, 1), (B * (1 + TW), 1, 1)).unbind(0)
-            trunc = flags.as_strided((n, B, TW), (B * (1 + TW), TW, 1), B).unbind(0)
-            sl.gym = list(zip(rew, term, trunc))
-            sl.gym_ptrs = [(base + (i * slot + S * Bp + obs_elems) * isz, fbase + i * B * (1 + TW),
-                            fbase + i * B * (1 + TW) + B) for i in range(n)]
-        # recycling bookkeeping (see the comment above _Slots)
-        sl.obs_width = O
-        sl.phys = [self.PhysicalState(*lv) for lv in sl.leaves]
-        sl.tens = [tuple(sl.leaves[i]) + (sl.obs[i],) + (tuple(sl.gym[i]) if gym else ()) for i in range(n)]
-        sl.objs = [sl.tens[i] + (sl.phys[i],) for i in range(n)]
-        sl.storages = [buf.untyped_storage()] + ([obuf.untyped_storage()] if obuf is not None else []) + ([flags.untyped_storage()] if gym else [])
-        sl.rc0 = sl.use0 = sl.stream = None
-        return sl
-
-    def _slot_is_free(self, sl, i: int, stream) -> bool:
-        if sl.rc0 is None or sl.stream != stream:
-            return False
-        if tuple(map(sys.getrefcount, sl.objs[i])) != sl.rc0[i]:
-            return False
-        tens = sl.tens[i]
-        if sum(map(CoreEnvironment._tensor_use_count, tens)) != len(tens):
-            return False
-        return [CoreEnvironment._storage_use_count(st._cdata) for st in sl.storages] == sl.use0
-
-    def _arm_recycling(self, sl, stream):
-        """Record the reference counts of a fresh pool (nothing outside `sl` refers to its tensors yet)."""
-        if CoreEnvironment._storage_use_count is None or CoreEnvironment._tensor_use_count is None:
-            return  # this torch build cannot tell whether a slot is still visible: never recycle
-        sl.stream = stream
-        sl.rc0 = [tuple(map(sys.getrefcount, o)) for o in sl.objs]
-        sl.use0 = [CoreEnvironment._storage_use_count(st._cdata) for st in sl.storages]
-
-    def _slots_per_alloc(self, gym: bool) -> int:
-        """Slots per pool: ~4 MiB worth, at most 32; never fewer than 3 (the input state, the output and one dead slot —
-        below that nothing can ever be recycled) unless three slots would exceed 1 GiB."""
-        isz = 4 if self.dtype == torch.float32 else 8
-        per = self.batch_size * (self.physical_state_dim + self._obs_dim() + (1 if gym else 0)) * isz
-        n = max(1, min(32, (4 << 20) // max(per, 1)))
-        if n < 3 and 3 * per <= (1 << 30):
-            n = 3
-        return n
-
+    # Per call: identity check of the incoming state leaves (did we return them last time? then their pointer array is already
+    # built), one data_ptr() for the action, one ctypes call with pre-built arguments, two small dataclass constructions. The
+    # output slot comes from _placement.StepSlotPool (fresh memory per call; a dead slot's tensor objects are used again).
     def _vmap_step_launch(self, state, action, gym: bool, obs_refs=None):
         B = self.batch_size
         dev = self.device
@@ -671,25 +568,10 @@ class CoreEnvironment(ABC):
             with torch.cuda.device(dev):
                 stream = _native.raw_stream(idx)
                 capturing = _cuda_is_capturing()
-        sl = None if capturing else self._slots[gym]
-        if sl is not None:
-            i = sl.i
-            if i >= sl.n:  # pool used up: its oldest slot again, if nothing can see that slot's tensors any more
-                i %= sl.n
-                if not self._slot_is_free(sl, i, stream):
-                    sl = None
-            if sl is not None and sl.obs_width != (self._obs_dim_cache[1] if self._obs_dim_cache and self._obs_dim_cache[0]
-                                                   == len(self.control_state) else self._obs_dim()):
-                sl = None
-        if sl is None:
-            sl = self._new_slots(1 if capturing else self._slots_per_alloc(gym), gym)
-            i = 0
-            if not capturing:  # memory allocated during capture belongs to the graph's pool: never handed out later
-                self._slots[gym] = sl
-                self._arm_recycling(sl, stream)
-        sl.i += 1
-        if self._pool_wait_events:  # pool_wait_stream(): a foreign stream still reads what an earlier call returned
-            self._pool_drain_waits()
+        oc = self._obs_dim_cache
+        sl, i = self._step_pool.take(gym, stream, capturing, oc[1] if oc and oc[0] == len(self.control_state) else self._obs_dim())
+        if self._placement.wait_events:  # pool_wait_stream(): a foreign stream still reads what an earlier call returned
+            self._placement.drain_waits()
         opts = self.launch_opts
         args = (self.ENV_ID, self._solver.id, 0 if self.dtype is torch.float32 else 1, B, ctypes.byref(props), control_ref,
                 self.tau, in_ptrs, action.data_ptr(), sl.out_ptrs[i], sl.obs_ptrs[i],
@@ -885,314 +767,26 @@ class CoreEnvironment(ABC):
                 f"(floating-point floor); returning the intended {K * sub + 1} rows", RuntimeWarning)
         return sub
 
-    def _run_sim_ahead(self, init_state, actions, env_properties, obs_stepsize, action_stepsize, B, want_gym=False, out=None):
-        S, A, OW = self.physical_state_dim, self.action_dim, self._obs_dim()
-        actions = torch.as_tensor(actions)
-        K = actions.shape[-2]
-        sub = self._n_substeps(K, obs_stepsize, action_stepsize)
-        N = K * sub
-        props, keep = self._props_for(env_properties, B)
-        st_in = [self._t(getattr(init_state.physical_state, n), (B,)) for n in self.STATE_FIELDS]
-        control, refs = self._control(init_state, (B,))
-
-        if actions.device != self.device or actions.dtype != self.dtype:
-            actions = actions.to(device=self.device, dtype=self.dtype)
-        T = _native.TILE
-        if actions.ndim == 4:  # [B/T, T, K, A] view over tiled [B/T, K, A, T] memory (new_actions_buffer(layout="tiled"))
-            assert tuple(actions.shape[:2]) == (B // T, T) and tuple(actions.stride()) == (K * A * T, 1, A * T, T), \
-                "4-D actions must come from new_actions_buffer(K, layout='tiled')"
-            a_layout = _native.LAYOUT_TILED
-        elif K > 0 and B > 0 and tuple(actions.stride()) == (1, A * B, B):
-            a_layout = _native.LAYOUT_LANE_MAJOR  # a [K, A, B] buffer viewed as [B, K, A]
-        else:
-            actions = actions.contiguous()
-            a_layout = _native.LAYOUT_ENV_MAJOR
-
-        want_states = self.store_state_trajectory
-        if self.traj_layout == "lane_major" and B > 0 and self.device.type == "cuda" and not (want_gym and out is not None):
-            # (with the gym trajectories too since round 4: their launches used to write unpooled, unplaced buffers — observations
-            # and seven leaves allocated back to back, the slow placement level — and cost 5.5 ... 6.4 ms where this path gives 5.5)
-            return self._run_sim_ahead_lane_major(init_state, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub,
-                                                  want_states, out, want_gym)
-        if out is not None:
-            raise ValueError("vmap_sim_ahead(out=...) is available for the default lane-major trajectories without gym outputs")
-        isz = 4 if self.dtype is torch.float32 else 8
-        if (self.traj_layout == "env_major" and not want_gym and B > 0 and self.device.type == "cuda"
-                and (OW + (S if want_states else 0)) * (N + 1) * B * isz >= self._PLACED_TRAJ_BYTES):
-            return self._run_sim_ahead_env_major_large(actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub, want_states)
-        if self.traj_layout == "lane_major":
-            obs_buf = torch.empty((N + 1, OW, B), dtype=self.dtype, device=self.device)
-            st_buf = [torch.empty((N + 1, B), dtype=self.dtype, device=self.device) for _ in range(S)] if want_states else None
-            t_layout = _native.LAYOUT_LANE_MAJOR
-            observations = obs_buf.permute(2, 0, 1)
-            st_views = [b.t() for b in st_buf] if want_states else None
-        elif self.traj_layout == "tiled":
-            # opt-in, NOT reference-shaped: tiles of T envs, each tile lane-major -> views [B/T, T, N+1, OW] / [B/T, T, N+1]
-            assert B % T == 0, f"traj_layout='tiled' needs batch_size % {T} == 0"
-            obs_buf = torch.empty((B // T, N + 1, OW, T), dtype=self.dtype, device=self.device)
-            st_buf = [torch.empty((B // T, N + 1, T), dtype=self.dtype, device=self.device) for _ in range(S)] if want_states else None
-            t_layout = _native.LAYOUT_TILED
-            observations = obs_buf.permute(0, 3, 1, 2)
-            st_views = [b.permute(0, 2, 1) for b in st_buf] if want_states else None
-        elif self.traj_layout == "env_major":
-            obs_buf = torch.empty((B, N + 1, OW), dtype=self.dtype, device=self.device)
-            st_buf = [torch.empty((B, N + 1), dtype=self.dtype, device=self.device) for _ in range(S)] if want_states else None
-            t_layout = _native.LAYOUT_ENV_MAJOR
-            observations, st_views = obs_buf, st_buf
-        else:
-            raise ValueError(f"traj_layout must be 'lane_major', 'env_major' or 'tiled', got {self.traj_layout!r}")
-        last = [torch.empty(B, dtype=self.dtype, device=self.device) for _ in range(S)]
-        sem = {"ahead": _native.SEM_AHEAD, "step": _native.SEM_STEP}[self.sim_ahead_semantics]
-        workspace = None
-        if self.env_major_workspace and B > 0 and _native.LAYOUT_ENV_MAJOR in (a_layout, t_layout):
-            # env-major (row-major) buffers: let the library transpose through a scratch buffer instead of issuing
-            # scattered 4-byte accesses (excenv_sim_ahead_ws)
-            nbytes = _native.sim_ahead_workspace_bytes(self.ENV_ID, self.dtype, B, K, sub, len(self.control_state),
-                                                       a_layout, t_layout, want_states)
-            if nbytes > 0:
-                workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        opts = self.launch_opts
-        if _native.LAYOUT_ENV_MAJOR in (a_layout, t_layout) and not self.env_major_fused:
-            opts = _native.launch_opts(opts.envs_per_lane if opts else 0, 1, opts.lds_pad_bytes if opts else 0)
-        gym_bufs = gym_out = None
-        if want_gym:  # reward / terminated / truncated trajectories from the same launch (excenv_traj_gym_t)
-            if t_layout == _native.LAYOUT_TILED:
-                raise ValueError("return_rew_trunc_term is not available with traj_layout='tiled'")
-            TW = _native.truncated_width(self.ENV_ID, len(self.control_state))
-            if t_layout == _native.LAYOUT_LANE_MAJOR:
-                rew = torch.empty((N, B), dtype=self.dtype, device=self.device)
-                term = torch.empty((N, B), dtype=torch.bool, device=self.device)
-                trunc = torch.empty((N + 1, TW, B), dtype=torch.bool, device=self.device)
-                gym_out = (rew.t()[..., None], trunc.permute(2, 0, 1), term.t()[..., None])
-            else:
-                rew = torch.empty((B, N, 1), dtype=self.dtype, device=self.device)
-                term = torch.empty((B, N, 1), dtype=torch.bool, device=self.device)
-                trunc = torch.empty((B, N + 1, TW), dtype=torch.bool, device=self.device)
-                gym_out = (rew, trunc, term)
-            gym_bufs = (rew, term, trunc)
-        _native.sim_ahead(self.ENV_ID, self._solver.id, self.dtype, B, K, sub, props, control, float(obs_stepsize),
-                          float(self.tau), st_in, actions, a_layout, obs_buf, st_buf, t_layout, last, sem, workspace, opts,
-                          gym_bufs)
-        if want_gym:
-            return observations, st_views, last, N, gym_out
-        return observations, st_views, last, N
-
-    # -- large trajectory outputs ----------------------------------------------------------------------------------------
-    # Where the driver places tens of GB of trajectory buffers in physical memory moves the trajectory kernel by 15-20 %
-    # (profiles/r03_placement_regions.md): device memory behaves as a few large physical regions, and write
-    # traffic that falls into ONE region at a time — observations and state leaves allocated back to back by a fresh process —
-    # runs at ~5.0 TB/s where the same kernel over buffers in two regions runs at ~5.9 TB/s; a plain sequential fill shows the
-    # same two levels, so this is the platform, not the kernel. Virtual addresses say nothing about the region, so a new set of
-    # output buffers is PLACED BY MEASUREMENT: the trajectory launch of the very call that needs the set is timed into
-    # (observations, candidate state block); while another candidate is made, the rejected block and a 16 GiB spacer (hipMalloc
-    # outside torch's cache) stay allocated, so that it lands a region further on. The first set of a shape tries at least two
-    # placements and stops when one is clearly (7 %) faster than another (both levels have shown themselves); later sets stop at
-    # the first block that matches the best time known; at most _PLACEMENT_TRIES candidates, the fastest is kept, everything else
-    # is freed. Cost: 3 launches per candidate, once per set. Sets are then pooled: a dead set (same test as the vmap_step
-    # slots: no Python reference, no C++ holder, no foreign view, same stream) is written again instead of allocating a new
-    # one, so a chained run (`obs, states, last = env.vmap_sim_ahead(last, actions, ...)`) alternates between two placed sets.
-    class _TrajSet:
-        __slots__ = ("key", "obs_buf", "st_buf", "lbuf", "observations", "st_views", "last", "obs_ptr", "traj_ptrs", "last_ptrs",
-                     "tens", "storages", "rc0", "use0", "stream", "placement", "ev", "ev_pending", "steady_ms", "uses")
-
-    _PLACED_TRAJ_BYTES = 1 << 30  # output sets at least this large go through the placement check
-    _PLACEMENT_TRIES = 4
-    _PLACEMENT_ACCEPT = 0.93      # fastest / slowest candidate at or below this: the two levels have both been seen
-    _TRAJ_POOL_SETS = 2
-
+    # -- large trajectory outputs: pooled and placed by _placement.TrajectoryPlacement -----------------------------------------------
     @classmethod
     def placement_memory_budget(cls, B: int, rows: int, OW: int, S: int, itemsize: int, free_bytes: int) -> dict:
-        """Upper bounds (bytes) of what pooling and placing the large output sets of one shape can hold on a device with
-        `free_bytes` free, for capacity planning (C5: 2^22 environments per GPU, 101 rows: 25.5 GB per set):
-          steady      : the pooled sets that stay allocated (_TRAJ_POOL_SETS sets: observations + state block + last states)
-          search_peak : the most a placement search holds at once on top of the OTHER pooled set — the new set's observations,
-                        up to _PLACEMENT_TRIES candidate state blocks and the spacers between them (each at most a third of what
-                        is free when it is taken, never more than _PLACEMENT_SPACER_BYTES)
-        A search that runs out of memory stops early and keeps the best candidate seen (torch.OutOfMemoryError is caught)."""
-        obs = rows * OW * B * itemsize
-        block = S * rows * B * itemsize
-        one = obs + block + S * B * itemsize
-        spacer = min(cls._PLACEMENT_SPACER_BYTES, max(free_bytes // 3, 0))
-        peak = obs + cls._PLACEMENT_TRIES * block + (cls._PLACEMENT_TRIES - 1) * spacer + spacer  # + the observation spacer of a replacement
-        return {"set": one, "steady": cls._TRAJ_POOL_SETS * one, "search_peak": 2 * one + peak,
-                "searches_at_most": 1 + cls._PLACEMENT_REPLACEMENTS + (cls._TRAJ_POOL_SETS - 1)}
+        """Upper bounds (bytes) of what the pooled, placed output sets of one shape can hold (TrajectoryPlacement.memory_budget)."""
+        return TrajectoryPlacement.memory_budget(B, rows, OW, S, itemsize, free_bytes)
 
     def release_trajectory_buffers(self):
         """Drop the pooled (dead) trajectory output sets so that their memory returns to torch's allocator."""
-        self._traj_sets = []
-        self._arena_made = set()  # the next large call starts over (arena pair first)
-
-    _PLACEMENT_REPLACEMENTS = 2
-    _REPLACE_RATIO = 1.05  # a pooled set this much slower than its sibling in real launches is up for replacement
-    _REPLACE_DECIDE_USES = 3  # ... but only while it has been timed at most this often: afterwards it stays (no search in a long run)
-    _PLACEMENT_SPACER_BYTES = 16 << 30  # a rejected block + this much memory stay allocated while the next block is made
-
-    # Round 4: a placement can be judged ABSOLUTELY. Over twelve placements of one process (tools/placement_classify.py) the
-    # launch time of the trajectory kernel follows the no-arithmetic pattern over the same buffers (excenv_stream_pattern: the
-    # launch's reads and writes, nothing else) with a correlation of -0.92 ... -0.93 for the headline, C2 and C4 alike, while a plain
-    # fill of the buffers runs at 6.7 ... 6.85 TB/s wherever they lie. In the fast level the pattern reaches 0.82 ... 0.84 of the
-    # fill rate (PMSM 5 590 ... 5 743 of 6 830 GB/s, C4 5 524 ... 5 637 of 6 720, C2 5 604 of 6 831), in the slow placements 0.70 ...
-    # 0.79. So a candidate is accepted when pattern / fill >= _PATTERN_ACCEPT, with no second placement to compare it with and
-    # no launch of the trajectory kernel itself (whose probes used to show up in every profile of the kernel).
-    _PATTERN_ACCEPT = 0.81
-
-    def _fill_rate(self, buf):
-        """GB/s of a plain fill of `buf` (once per environment: it does not depend on where the buffer lies)."""
-        if self._fill_gbs is None:
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            buf.fill_(0)
-            for e in ev[:-1]:
-                e.record()
-                buf.fill_(0)
-            ev[-1].record()
-            ev[-1].synchronize()
-            ms = min(float(a.elapsed_time(b)) for a, b in zip(ev[:-1], ev[1:]))
-            self._fill_gbs = buf.numel() * buf.element_size() / ms / 1e6
-        return self._fill_gbs
-
-    def _pattern_score(self, obs_buf, block_ptr, leaf_e, B, rows, OW, S, isz, act_ptr, A):
-        """(ms, pattern rate / fill rate) of the trajectory launch's access pattern over (obs_buf, the state block at block_ptr)."""
-        rb = B * isz
-        ob = obs_buf.data_ptr()
-        wr = [ob + c * rb for c in range(OW)] + [block_ptr + j * leaf_e * isz for j in range(S)]
-        wrs = [OW * rb] * OW + [rb] * S
-        rd, rds = [act_ptr + c * rb for c in range(A)], [A * rb] * A
-        R = rows - 2
-        stream = _native._raw_stream(self.device)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        with _native._on_device(self.device):
-            _native.stream_pattern(rd, rds, wr, wrs, rb, R, stream)
-            for e in ev[:-1]:
-                e.record()
-                _native.stream_pattern(rd, rds, wr, wrs, rb, R, stream)
-            ev[-1].record()
-        ev[-1].synchronize()
-        ms = min(float(a.elapsed_time(b)) for a, b in zip(ev[:-1], ev[1:]))
-        return ms, ((A + OW + S) * rb * R / ms / 1e6) / self._fill_rate(obs_buf)
-
-    def _place_state_block(self, obs_buf, B, rows, OW, S, isz, time_launch, block_shape=None, known_ms=None, pattern=None):
-        """A [S, rows, B] block for the state leaves of a new set whose traffic, together with the observations', does not fall
-        into one physical region (see above). `time_launch(block)` runs the trajectory launch of the current call into
-        (obs_buf, block) and returns its time in ms. Returns (block, diagnostics)."""
-        dt, dev = self.dtype, self.device
-        block_shape = (S, rows, B) if block_shape is None else block_shape  # env-major sets: (S, padded leaf elements)
-        block = torch.empty(block_shape, dtype=dt, device=dev)
-        nbytes = (OW + S) * rows * B * isz
-        if (self.trajectory_placement not in ("auto", "search") or (time_launch is None and pattern is None) or nbytes < self._PLACED_TRAJ_BYTES
-                or torch.cuda.is_current_stream_capturing()):
-            return block, None
-        pkey = (B, rows, OW, S) + (() if len(block_shape) == 3 else ("env_major",))
-        known = self._placement_best.get(pkey) if known_ms is None else known_ms  # known_ms: a sibling set's steady-state time
-        tried, spacers = [], []
-        try:
-            # smaller blocks are cheap to probe and their first candidates land in the slow level more often (C2: all four in
-            # one of two fresh processes): two more tries
-            tries = self._PLACEMENT_TRIES + (2 if S * rows * B * isz <= (10 << 30) else 0)
-            ratios = []
-            for k in range(tries):
-                if pattern is not None:  # judged absolutely: the no-arithmetic pattern against the fill rate
-                    t, ratio = pattern(block)
-                    ratios.append(round(ratio, 4))
-                else:
-                    t = time_launch(block)
-                tried.append((t, block))
-                times = [x for x, _ in tried]
-                if pattern is not None:
-                    good = ratio >= self._PATTERN_ACCEPT
-                elif known is not None:
-                    good = t <= 1.02 * known
-                else:
-                    good = len(times) >= 2 and min(times) <= self._PLACEMENT_ACCEPT * max(times)
-                if good or k == tries - 1:
-                    break
-                # Blocks torch holds in its cache (an earlier set's rejected candidates, for one) would be handed out again at
-                # their old addresses whatever the spacer does: they go back to the driver first (cached, unused memory only;
-                # once per search).
-                if k == 0:
-                    torch.cuda.empty_cache()
-                # the spacer never takes more than a third of what the device has free right now (other processes may share it)
-                free_b = torch.cuda.mem_get_info(dev)[0]
-                want_b = req_b = max(self._PLACEMENT_SPACER_BYTES - S * rows * B * isz, 1 << 20)
-                if free_b < 3 * (want_b + S * rows * B * isz):
-                    want_b = max(0, free_b // 3 - S * rows * B * isz)
-                if want_b < min(req_b, 1 << 30):
-                    break  # not enough room to move the next candidate a region further: keep the best seen so far
-                with _native._on_device(dev):
-                    sp = _native.raw_malloc(want_b)
-                if sp is not None:
-                    spacers.append(sp)
-                try:
-                    block = torch.empty(block_shape, dtype=dt, device=dev)
-                except torch.OutOfMemoryError:
-                    break
-        finally:
-            for sp in spacers:
-                _native.raw_free(sp)
-        t_best, best = min(tried, key=lambda tb: tb[0])
-        chosen = [t for t, _ in tried].index(t_best)
-        if pattern is not None:
-            diag = {"candidate_pattern_ms": [round(t, 4) for t, _ in tried], "candidate_pattern_over_fill": ratios, "chosen": chosen,
-                    "pattern_over_fill": ratios[chosen], "accept_at": self._PATTERN_ACCEPT, "fill_gbs": round(self._fill_gbs, 1),
-                    "what": "no-arithmetic access pattern of the launch (excenv_stream_pattern) timed over (observations, candidate "
-                            "state block) against the fill rate; rejected blocks and a spacer stay allocated while the next "
-                            "candidate is made"}
-        else:
-            self._placement_best[pkey] = t_best if known is None else min(known, t_best)
-            diag = {"candidate_ms": [round(t, 4) for t, _ in tried], "chosen": chosen, "chosen_ms": t_best,
-                    "best_known_ms_before": known, "spacer_gib": self._PLACEMENT_SPACER_BYTES / 2**30,
-                    "what": "trajectory launch of the call timed into (observations, candidate state block); rejected blocks and a "
-                            "spacer stay allocated while the next candidate is made"}
-        del tried, block
-        return best, diag
-
-    def _traj_note_launch(self, ts):
-        """Read the HIP events of the previous real launch into a pooled set (finished long ago when the set comes round again)."""
-        if ts.ev_pending and ts.ev is not None and ts.ev[1].query():
-            ms = float(ts.ev[0].elapsed_time(ts.ev[1]))
-            ts.ev_pending = False
-            ts.uses += 1
-            ts.steady_ms = ms if ts.steady_ms is None else min(ts.steady_ms, ms)
-
-    def _traj_timed_launch(self, ts, launch_fn, nbytes):
-        """Launch into a pooled, placed set with a pair of HIP events around it (two event records per multi-millisecond launch)."""
-        timed = (ts.rc0 is not None and self.trajectory_placement in ("auto", "search") and nbytes >= self._PLACED_TRAJ_BYTES
-                 and not torch.cuda.is_current_stream_capturing())
-        if not timed:
-            launch_fn()
-            return
-        self._traj_note_launch(ts)
-        if ts.ev is None:
-            ts.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        if ts.ev_pending:  # the previous launch has not finished yet (back-to-back reuse through out=...): leave its events alone
-            launch_fn()
-            return
-        ts.ev[0].record()
-        launch_fn()
-        ts.ev[1].record()
-        ts.ev_pending = True
+        self._placement.release()
 
     @property
     def trajectory_placement_settled(self) -> bool:
-        """True once the pooled large output sets have all been timed in real launches and none is up for replacement: a caller
-        that wants steady timings (bench.py) steps until then. Always True when nothing is pooled or placed."""
-        if not self._traj_sets or self.trajectory_placement not in ("auto", "search") or not self.trajectory_pool:
-            return True
-        for ts in self._traj_sets:
-            self._traj_note_launch(ts)
-        by_key = {}
-        for ts in self._traj_sets:
-            by_key.setdefault(ts.key, []).append(ts)
-        for key, sets in by_key.items():
-            if len(sets) < self._TRAJ_POOL_SETS or any(t.steady_ms is None for t in sets):
-                return False
-            ms = [t.steady_ms for t in sets]
-            big = key[1] * (key[2] + key[3]) * key[0] * (4 if key[5] is torch.float32 else 8) >= (1 << 30)  # only such sets are replaced
-            # a set can only be replaced during its first _REPLACE_DECIDE_USES timed launches: until every set is past that window
-            # (or the replacements of the shape are used up) a later call may still run a placement search
-            if (big and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS
-                    and any(t.uses <= self._REPLACE_DECIDE_USES for t in sets)):
-                return False
-        return True
+        """True once no later call of the shapes seen so far can run a placement search: a caller that wants steady timings
+        (bench.py) steps until then. Always True when nothing is pooled or placed."""
+        return self._placement.settled
+
+    @property
+    def last_placement(self):
+        """Diagnostics of the most recent placement decision (dict) or None."""
+        return self._placement.last
 
     def pool_wait_stream(self, stream=None):
         """Tell the output pools that `stream` (default: the current stream) is still reading tensors an earlier call returned:
@@ -1200,394 +794,7 @@ class CoreEnvironment(ABC):
         up to now. The pools see Python references, C++ holders and views — not `Tensor.record_stream`; a consumer on a side
         stream that drops its reference early calls this (or keeps the reference until it has synchronised, or switches the pools
         off: `trajectory_pool = False`)."""
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device) if stream is None else stream)
-        self._pool_wait_events.append(ev)
-
-    def _pool_drain_waits(self):
-        if self._pool_wait_events:
-            cur = torch.cuda.current_stream(self.device)
-            for ev in self._pool_wait_events:
-                cur.wait_event(ev)
-            self._pool_wait_events = []
-
-    def _traj_set_is_free(self, ts, stream) -> bool:
-        if ts.rc0 is None or ts.stream != stream:
-            return False
-        if tuple(map(sys.getrefcount, ts.tens)) != ts.rc0:
-            return False
-        if sum(map(CoreEnvironment._tensor_use_count, ts.tens)) != len(ts.tens):
-            return False
-        return [CoreEnvironment._storage_use_count(st._cdata) for st in ts.storages] == ts.use0
-
-    def _traj_set_for(self, B, rows, OW, S, want_states, last_e, isz, launch, env_major=False, pattern_ctx=None):
-        """env_major: the reference's row-major arrays (observations [B, rows, OW], state leaves [B, rows], every leaf starting on
-        a 128-byte boundary of one block) instead of views of lane-major memory; pooled and placed the same way."""
-        dt, dev = self.dtype, self.device
-        key = (B, rows, OW, S, want_states, dt) + (("env_major",) if env_major else ())
-        pkey = (B, rows, OW, S) + (("env_major",) if env_major else ())
-        leaf_e = (rows * B * isz + 127) // 128 * 128 // isz if env_major else rows * B  # elements between consecutive leaves
-        capturing = torch.cuda.is_current_stream_capturing()
-        pooled = (self.trajectory_pool and not capturing and CoreEnvironment._storage_use_count is not None
-                  and CoreEnvironment._tensor_use_count is not None)
-        stream = _native._raw_stream(dev)
-        replacing = None
-        if pooled:
-            for k, ts in enumerate(self._traj_sets):
-                if ts.key == key and self._traj_set_is_free(ts, stream):
-                    # A dead set that runs clearly slower than its sibling is not worth keeping: it is dropped and a new one is placed
-                    # against the sibling's time (at most _PLACEMENT_REPLACEMENTS times per shape). What counts is the time of the
-                    # REAL launches into each set (HIP events around every large launch, read when the set comes round again): round 3
-                    # compared the times of the placement probes, accepted a second set at 5.09 ms next to a first one that had probed
-                    # at 5.04 — and the two then ran at 5.11 and 4.87 ms, call after call.
-                    self._traj_note_launch(ts)
-                    sib = [t.steady_ms for t in self._traj_sets if t is not ts and t.key == key and t.steady_ms is not None]
-                    best = min(sib) if sib else self._placement_best.get(pkey)
-                    ms = ts.steady_ms if (sib and ts.steady_ms is not None) else (ts.placement or {}).get("chosen_ms")
-                    if (best is not None and ms is not None and ms > self._REPLACE_RATIO * best and (OW + S) * rows * B * isz >= (1 << 30)
-                            and ts.uses <= self._REPLACE_DECIDE_USES  # decided early, never in the middle of a long run
-                            and self._placement_replaced.get(key, 0) < self._PLACEMENT_REPLACEMENTS and launch is not None
-                            and self.trajectory_placement in ("auto", "search")):
-                        self._placement_replaced[key] = self._placement_replaced.get(key, 0) + 1
-                        self._placement_target = best if sib else None
-                        replacing = self._traj_sets.pop(k)  # stays alive until the new set has shown that it is faster
-                        break
-                    self._traj_sets.append(self._traj_sets.pop(k))  # most recently used last
-                    return ts
-            self._traj_sets = [t for t in self._traj_sets if t.key == key][-(self._TRAJ_POOL_SETS - 1):] if self._TRAJ_POOL_SETS > 1 else []
-        if (pooled and want_states and (not env_major or self._ARENA_ENV_MAJOR) and self.trajectory_placement == "auto"
-                and self._placement_target is None
-                and self._TRAJ_POOL_SETS == 2 and not self._traj_sets and key not in self._arena_made
-                and (OW + S) * rows * B * isz >= max(self._PLACED_TRAJ_BYTES, self._ARENA_MIN_SET_BYTES)):
-            pair = self._traj_arena_pair(key, B, rows, OW, S, last_e, isz, stream, env_major, pattern_ctx)
-            if pair is not None:
-                return pair
-        ts = CoreEnvironment._TrajSet()
-        ts.key = key
-        ts.ev, ts.ev_pending, ts.steady_ms, ts.uses = None, False, None, 0
-        known_ms, self._placement_target = self._placement_target, None
-        obs_spacer = None
-        if known_ms is not None:
-            # replacement of a set that ran slower than its sibling: its observation buffer moves as well — torch would hand the
-            # block just released straight back, so the cache is emptied and a bounded spacer taken first (freed below)
-            torch.cuda.empty_cache()
-            free_b = torch.cuda.mem_get_info(dev)[0]
-            want_b = min(self._PLACEMENT_SPACER_BYTES, free_b // 3 - (OW + S) * rows * B * isz)
-            if want_b >= (1 << 30):
-                with _native._on_device(dev):
-                    obs_spacer = _native.raw_malloc((self._placement_replaced.get(key, 1) % 2 + 1) * want_b // 2)
-        try:
-            ts.obs_buf = torch.empty((B, rows, OW) if env_major else (rows, OW, B), dtype=dt, device=dev)
-        except torch.OutOfMemoryError:
-            # dead pooled sets live outside torch's cache: give them (and the cache) back and try once more
-            self._traj_sets = []
-            torch.cuda.empty_cache()
-            ts.obs_buf = torch.empty((B, rows, OW) if env_major else (rows, OW, B), dtype=dt, device=dev)
-        finally:
-            if obs_spacer is not None:
-                _native.raw_free(obs_spacer)
-        ts.placement = None
-        ts.lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
-        lb = ts.lbuf.data_ptr()
-        ts.last_ptrs = _native.ptr_array([lb + j * last_e * isz for j in range(S)])
-        ts.obs_ptr = ts.obs_buf.data_ptr()
-        if want_states:
-            def time_launch(block):
-                ptrs = _native.ptr_array([block.data_ptr() + j * leaf_e * isz for j in range(S)])
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-                launch(ts.obs_ptr, ptrs, ts.last_ptrs)  # warm (clocks, TLB)
-                for e in ev[:-1]:  # two timed launches, the faster counts: the first ones of a process run a few % slow
-                    e.record()
-                    launch(ts.obs_ptr, ptrs, ts.last_ptrs)
-                ev[-1].record()
-                ev[-1].synchronize()
-                return min(float(a.elapsed_time(b)) for a, b in zip(ev[:-1], ev[1:]))
-
-            # a set that is not pooled is written once: probing its placement (four extra launches per candidate) would never pay
-            pattern = None
-            if pattern_ctx is not None and pooled and not env_major and (B * isz) % 16 == 0 and rows >= 10:
-                pattern = lambda block: self._pattern_score(ts.obs_buf, block.data_ptr(), leaf_e, B, rows, OW, S, isz, *pattern_ctx)
-            try:
-                ts.st_buf, ts.placement = self._place_state_block(ts.obs_buf, B, rows, OW, S, isz,
-                                                                  time_launch if (launch is not None and pooled) else None,
-                                                                  (S, leaf_e) if env_major else None, known_ms, pattern)
-            except torch.OutOfMemoryError:
-                self._traj_sets = []
-                torch.cuda.empty_cache()
-                ts.st_buf, ts.placement = self._place_state_block(ts.obs_buf, B, rows, OW, S, isz, None,
-                                                                  (S, leaf_e) if env_major else None)
-            self.last_placement = ts.placement
-            sb = ts.st_buf.data_ptr()
-            if env_major:
-                ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (leaf_e, rows, 1)).unbind(0))
-            else:
-                ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (rows * B, 1, B)).unbind(0))
-            ts.traj_ptrs = _native.ptr_array([sb + j * leaf_e * isz for j in range(S)])
-        else:
-            ts.st_buf, ts.st_views, ts.traj_ptrs = None, None, None
-        ts.observations = ts.obs_buf[:] if env_major else ts.obs_buf.permute(2, 0, 1)  # a view object of its own (liveness test)
-        ts.last = tuple(ts.lbuf[:, :B].unbind(0))
-        ts.tens = (ts.observations,) + (ts.st_views or ()) + ts.last
-        ts.storages = [t.untyped_storage() for t in ((ts.obs_buf, ts.lbuf) + ((ts.st_buf,) if want_states else ()))]
-        ts.rc0 = ts.use0 = ts.stream = None
-        if replacing is not None:
-            # the searched replacement must beat the set it replaces in the same currency (its probe time against the old set's
-            # real launches, which run a little faster than probes): otherwise the old set stays
-            new_ms = (ts.placement or {}).get("chosen_ms")
-            new_ratio, old_ratio = (ts.placement or {}).get("pattern_over_fill"), (replacing.placement or {}).get("pattern_over_fill")
-            if new_ratio is not None:  # judged by the pattern: the new set must be clearly better placed than the old one was
-                keep_old = old_ratio is not None and new_ratio < old_ratio + 0.015
-            else:
-                keep_old = new_ms is None or replacing.steady_ms is None or new_ms > 0.99 * replacing.steady_ms
-            if keep_old:
-                self._traj_sets.append(replacing)
-                if ts.placement is not None:
-                    ts.placement["kept_old_set_ms"] = replacing.steady_ms
-                    self.last_placement = ts.placement
-                return replacing
-        if pooled:
-            ts.stream = stream
-            ts.rc0 = tuple(map(sys.getrefcount, ts.tens))
-            ts.use0 = [CoreEnvironment._storage_use_count(st._cdata) for st in ts.storages]
-            self._traj_sets.append(ts)
-        return ts
-
-    # Deterministic placement of the FIRST two sets of a shape (round 4): one arena laid out
-    #     [observations A | observations B | (gap) | state block A | state block B]
-    # A launch's two kinds of write streams — 8 observation components, 7 state leaves — then start at least _ARENA_MIN_DISTANCE
-    # apart inside one large allocation, which is what turned the slow placement level into the fast one in every experiment of
-    # profiles/r03_placement_regions.md (>= 16 GiB between observations and leaves); tools/placement_arena.py: 0.709 / 0.716 of the
-    # roof for the two sets of the headline launch with no gap at all (the other set's observations ARE the distance), against 0.64
-    # ... 0.73 for hand-made gaps of 16 ... 96 GiB and 0.70 ... 0.73 for searched placements. No probe launches, no spacers, no
-    # empty_cache(), and the two sets run alike. The search (timing the launch into candidate blocks) remains the way a THIRD set is
-    # made (a caller that holds on to outputs) and the way a set is replaced whose real launches run > 3 % slower than its
-    # sibling's. Price: both sets are views of one allocation — holding a single returned tensor keeps all of it alive
-    # (`trajectory_placement = "search"` restores one allocation per returned array).
-    _ARENA_MIN_DISTANCE = 17 << 30
-    _ARENA_MIN_SET_BYTES = 4 << 30  # smaller sets would be mostly gap: they keep the search
-
-    _ARENA_ENV_MAJOR = os.environ.get("EXCENV_EM_ARENA", "1") != "0"  # row-major (reference-shaped) sets take the arena too
-
-    def _traj_arena_pair(self, key, B, rows, OW, S, last_e, isz, stream, env_major=False, pattern_ctx=None):
-        dt, dev = self.dtype, self.device
-        up = lambda n: (n + 63) // 64 * 64  # every sub-buffer starts on a 256-byte boundary
-        leaf_e = (rows * B * isz + 127) // 128 * 128 // isz if env_major else rows * B  # elements between consecutive leaves
-        obs_e, blk_e = up(rows * OW * B), up(S * leaf_e)
-        near = min(2 * obs_e, obs_e + blk_e) * isz  # distance observations -> state block of set A / set B
-        if near < self._ARENA_MIN_DISTANCE:
-            return None  # the other set's observations are not enough distance (an artificial gap measured 0.57 for C2): search
-        gap_e = 0
-        total = 2 * obs_e + gap_e + 2 * blk_e
-        if total * isz > torch.cuda.mem_get_info(dev)[0] * 0.8:
-            return None  # not worth crowding the device: the searched single sets take over
-        try:
-            arena = torch.empty(total, dtype=dt, device=dev)
-        except torch.OutOfMemoryError:
-            return None
-        self._arena_made.add(key)
-        sets = []
-        for k in range(2):
-            ts = CoreEnvironment._TrajSet()
-            ts.key = key
-            ts.ev, ts.ev_pending, ts.steady_ms, ts.uses = None, False, None, 0
-            ts.obs_buf = arena[k * obs_e: k * obs_e + rows * OW * B].view((B, rows, OW) if env_major else (rows, OW, B))
-            b0 = 2 * obs_e + gap_e + k * blk_e
-            ts.st_buf = arena[b0: b0 + S * leaf_e].view((S, leaf_e) if env_major else (S, rows, B))
-            ts.placement = {"arena_gib": round(total * isz / 2**30, 2), "gap_gib": round(gap_e * isz / 2**30, 2), "set": k,
-                            "what": "one arena [obs A | obs B | gap | states A | states B]: no probe launches"}
-            ts.lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
-            lb, sb = ts.lbuf.data_ptr(), ts.st_buf.data_ptr()
-            ts.last_ptrs = _native.ptr_array([lb + j * last_e * isz for j in range(S)])
-            ts.obs_ptr = ts.obs_buf.data_ptr()
-            if env_major:
-                ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (leaf_e, rows, 1)).unbind(0))
-                ts.observations = ts.obs_buf[:]
-            else:
-                ts.st_views = tuple(ts.st_buf.as_strided((S, B, rows), (rows * B, 1, B)).unbind(0))
-                ts.observations = ts.obs_buf.permute(2, 0, 1)
-            ts.traj_ptrs = _native.ptr_array([sb + j * leaf_e * isz for j in range(S)])
-            ts.last = tuple(ts.lbuf[:, :B].unbind(0))
-            ts.tens = (ts.observations,) + ts.st_views + ts.last
-            ts.storages = [arena.untyped_storage(), ts.lbuf.untyped_storage()]
-            ts.stream = stream
-            sets.append(ts)
-        if pattern_ctx is not None and not env_major and (B * isz) % 16 == 0 and rows >= 10:
-            # both sets must be in the fast level by the absolute criterion, else the arena goes back and the sets are searched
-            for ts in sets:
-                ms, ratio = self._pattern_score(ts.obs_buf, ts.st_buf.data_ptr(), leaf_e, B, rows, OW, S, isz, *pattern_ctx)
-                ts.placement["pattern_over_fill"] = round(ratio, 4)
-                ts.placement["pattern_ms"] = round(ms, 4)
-            if min(t.placement["pattern_over_fill"] for t in sets) < self._PATTERN_ACCEPT:
-                self.last_placement = {"arena_rejected": [t.placement["pattern_over_fill"] for t in sets], "accept_at": self._PATTERN_ACCEPT}
-                del sets, arena
-                torch.cuda.empty_cache()
-                return None
-        del arena
-        for ts in sets:  # the counts of an untouched pair: every view of both sets exists, nothing outside refers to any
-            ts.rc0 = tuple(map(sys.getrefcount, ts.tens))
-        for ts in sets:
-            ts.use0 = [CoreEnvironment._storage_use_count(st._cdata) for st in ts.storages]
-        self._traj_sets.extend(reversed(sets))  # set B waits in the pool (dead: nothing refers to it), set A is handed out
-        self.last_placement = sets[0].placement
-        return sets[0]
-
-    def _run_sim_ahead_env_major_large(self, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub, want_states):
-        """Row-major (reference-shaped) trajectories of at least _PLACED_TRAJ_BYTES: the fused env-major kernels write scattered
-        runs and depend on where observations and state leaves lie even more than the lane-major kernel does
-        (tools/em_placement.py: 7.0 ... 10.9 ms for the same launch), so these sets are pooled and placed like the lane-major
-        ones."""
-        S, OW = self.physical_state_dim, self._obs_dim()
-        N = K * sub
-        rows = N + 1
-        dt, dev = self.dtype, self.device
-        isz = 4 if dt is torch.float32 else 8
-        last_e = (B * isz + 15) // 16 * 16 // isz
-        opts = self.launch_opts
-        if not self.env_major_fused:
-            opts = _native.launch_opts(opts.envs_per_lane if opts else 0, 1, opts.lds_pad_bytes if opts else 0)
-        ws = ws_ptr = None
-        ws_bytes = 0
-        if self.env_major_workspace:
-            ws_bytes = _native.sim_ahead_workspace_bytes(self.ENV_ID, dt, B, K, sub, len(self.control_state), a_layout,
-                                                         _native.LAYOUT_ENV_MAJOR, want_states)
-            if ws_bytes > 0:
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)  # stream-ordered: free to die when this function returns
-                ws_ptr = ws.data_ptr()
-        sem = _native.SEM_AHEAD if self.sim_ahead_semantics == "ahead" else _native.SEM_STEP
-        st_in_ptrs = _native._ptrs(st_in)
-
-        def launch(o_ptr, t_ptrs, l_ptrs):
-            with _native._on_device(dev):
-                _native.sim_ahead_raw(self.ENV_ID, self._solver.id, 0 if dt is torch.float32 else 1, B, K, sub, ctypes.byref(props),
-                                      ctypes.byref(control) if control is not None else None, float(obs_stepsize), float(self.tau),
-                                      st_in_ptrs, actions.data_ptr() if K > 0 else None, a_layout, o_ptr,
-                                      t_ptrs if want_states else None, _native.LAYOUT_ENV_MAJOR, l_ptrs, sem, ws_ptr,
-                                      ws_bytes if ws_ptr is not None else 0, None if opts is None else ctypes.byref(opts),
-                                      _native._raw_stream(dev))
-
-        ts = self._traj_set_for(B, rows, OW, S, want_states, last_e, isz, launch, env_major=True)
-        self._pool_drain_waits()
-        self._traj_timed_launch(ts, lambda: launch(ts.obs_ptr, ts.traj_ptrs, ts.last_ptrs), (OW + (S if want_states else 0)) * rows * B * isz)
-        return ts.observations, ts.st_views, ts.last, N
-
-    # Trajectories up to this size come out of ONE allocation (observations, state leaves and last_state are views of it):
-    # at RL / MPC batch sizes the launch takes ~100 us and 2 S + 1 allocator calls plus as many view objects cost as much.
-    # Larger outputs keep one allocation per returned array so that dropping the states frees their memory.
-    _SHARED_TRAJ_BYTES = 32 << 20
-
-    def _run_sim_ahead_lane_major(self, init_state, actions, a_layout, props, control, st_in, obs_stepsize, B, K, sub,
-                                  want_states, out=None, want_gym=False):
-        """The default layout: buffers carved from one or two allocations, pointers computed from the base address, one ctypes call
-        with plain arguments (same launch as the general path above). want_gym: the reward / terminated / truncated trajectories
-        come from the same launch into arrays of their own (returned as a fifth element)."""
-        S, OW = self.physical_state_dim, self._obs_dim()
-        N = K * sub
-        rows = N + 1
-        dt, dev = self.dtype, self.device
-        isz = 4 if dt is torch.float32 else 8
-        al = 16 // isz
-        up = lambda n: (n + al - 1) // al * al
-        obs_e, leaf_e, last_e = up(rows * OW * B), up(rows * B), up(B)
-        traj_e = obs_e + (S * leaf_e if want_states else 0)
-        opts = self.launch_opts
-        ws_e = ws_bytes = 0
-        if a_layout == _native.LAYOUT_ENV_MAJOR:
-            # row-major actions (a plain [B, K, A] tensor, what the reference's call hands over): large batches of broadcast-
-            # property environments read them inside the trajectory kernel (per-wave LDS piece ring, DESIGN.md §4.1b); the rest
-            # is transposed through scratch by the library
-            if not self.env_major_fused:
-                opts = _native.launch_opts(opts.envs_per_lane if opts else 0, 1, opts.lds_pad_bytes if opts else 0,
-                                           (opts.flags if opts else 0) | _native.OPT_NO_FUSED_ACTIONS)
-            fk = (B, K, sub, len(self.control_state), actions.data_ptr() % 16, id(props),
-                  None if opts is None else (opts.envs_per_lane, opts.flags))
-            if self._fused_actions_cache is None or self._fused_actions_cache[0] != fk:
-                self._fused_actions_cache = (fk, _native.sim_ahead_fuses_actions(
-                    self.ENV_ID, self._solver.id, dt, B, K, props, len(self.control_state), False, a_layout,
-                    _native.LAYOUT_LANE_MAJOR, actions.data_ptr(), opts))
-            if self.env_major_workspace and not self._fused_actions_cache[1]:
-                wk = (B, K, sub, len(self.control_state), want_states)
-                if self._ws_bytes_cache is None or self._ws_bytes_cache[0] != wk:
-                    self._ws_bytes_cache = (wk, _native.sim_ahead_workspace_bytes(
-                        self.ENV_ID, dt, B, K, sub, len(self.control_state), a_layout, _native.LAYOUT_LANE_MAJOR, want_states))
-                ws_bytes = self._ws_bytes_cache[1]
-                ws_e = up((ws_bytes + isz - 1) // isz)
-        shared = (traj_e + S * last_e + ws_e) * isz <= self._SHARED_TRAJ_BYTES
-        st_views = None
-        traj_ptrs = None
-        ws_ptr = None
-        sem = _native.SEM_AHEAD if self.sim_ahead_semantics == "ahead" else _native.SEM_STEP
-        st_in_ptrs = _native._ptrs(st_in)
-
-        gym_out = gym_ref = None
-        if want_gym:  # excenv_traj_gym_t, lane-major: reward / terminated [N][B], truncated [N + 1][TW][B]
-            TW = _native.truncated_width(self.ENV_ID, len(self.control_state))
-            rew = torch.empty((N, B), dtype=dt, device=dev)
-            term = torch.empty((N, B), dtype=torch.bool, device=dev)
-            trunc = torch.empty((N + 1, TW, B), dtype=torch.bool, device=dev)
-            gym_out = (rew.t()[..., None], trunc.permute(2, 0, 1), term.t()[..., None])
-            gym_struct = _native.TrajGym(rew.data_ptr(), term.data_ptr(), trunc.data_ptr())
-            gym_ref = ctypes.byref(gym_struct)
-        done = (lambda *r: r + (gym_out,)) if want_gym else (lambda *r: r)
-
-        def launch(o_ptr, t_ptrs, l_ptrs):  # the trajectory launch of this call into the given output buffers
-            with _native._on_device(dev):
-                _native.sim_ahead_raw(self.ENV_ID, self._solver.id, 0 if dt is torch.float32 else 1, B, K, sub, ctypes.byref(props),
-                                      ctypes.byref(control) if control is not None else None, float(obs_stepsize), float(self.tau),
-                                      st_in_ptrs, actions.data_ptr() if K > 0 else None, a_layout, o_ptr,
-                                      t_ptrs if want_states else None, _native.LAYOUT_LANE_MAJOR, l_ptrs, sem, ws_ptr,
-                                      ws_bytes if ws_ptr is not None else 0, None if opts is None else ctypes.byref(opts),
-                                      _native._raw_stream(dev), gym_ref)
-
-        if out is not None:
-            # the caller hands back what an earlier call of the same shape returned: same buffers, no allocation
-            observations, o_states, o_last = out
-            on_dev = lambda t: t.device.type == dev.type and (dev.index is None or t.device.index == dev.index)
-            ok = (isinstance(observations, torch.Tensor) and observations.dtype is dt and on_dev(observations)
-                  and tuple(observations.shape) == (B, rows, OW) and tuple(observations.stride()) == (1, OW * B, B))
-            last = tuple(getattr(o_last.physical_state, n) for n in self.STATE_FIELDS)
-            ok = ok and all(isinstance(t, torch.Tensor) and t.dtype is dt and on_dev(t) and tuple(t.shape) == (B,)
-                            and t.is_contiguous() for t in last)
-            if want_states:
-                ok = ok and o_states is not None
-                st_views = tuple(getattr(o_states.physical_state, n) for n in self.STATE_FIELDS) if ok else None
-                ok = ok and all(isinstance(t, torch.Tensor) and t.dtype is dt and on_dev(t)
-                                and tuple(t.shape) == (B, rows) and tuple(t.stride()) == (1, B) for t in st_views)
-            if not ok:
-                raise ValueError("vmap_sim_ahead(out=...): pass the (observations, states, last_state) an earlier call with the "
-                                 "same batch, horizon, layout and dtype returned")
-            obs_ptr = observations.data_ptr()
-            if want_states:
-                traj_ptrs = _native._ptrs(st_views)
-            last_ptrs = _native._ptrs(last)
-            if ws_e:
-                ws = torch.empty(ws_e, dtype=dt, device=dev)
-                ws_ptr = ws.data_ptr()
-        elif shared:
-            buf = torch.empty(traj_e + S * last_e + ws_e, dtype=dt, device=dev)
-            base = buf.data_ptr()
-            if ws_e:
-                ws_ptr = base + (traj_e + S * last_e) * isz
-            observations = buf.as_strided((B, rows, OW), (1, OW * B, B))
-            if want_states:
-                st_views = buf.as_strided((S, B, rows), (leaf_e, 1, B), obs_e).unbind(0)
-                traj_ptrs = _native.ptr_array([base + (obs_e + j * leaf_e) * isz for j in range(S)])
-            last = buf.as_strided((S, B), (last_e, 1), traj_e).unbind(0)
-            last_ptrs = _native.ptr_array([base + (traj_e + j * last_e) * isz for j in range(S)])
-            obs_ptr = base
-        else:
-            if ws_e:
-                ws = torch.empty(ws_e, dtype=dt, device=dev)  # stream-ordered: free to die when this function returns
-                ws_ptr = ws.data_ptr()
-            # lane-major actions: the launch's access pattern can be replayed without arithmetic to judge a placement
-            pctx = (actions.data_ptr(), self.action_dim) if (a_layout == _native.LAYOUT_LANE_MAJOR and sub == 1 and K >= 9) else None
-            ts = self._traj_set_for(B, rows, OW, S, want_states, last_e, isz, lambda o, t, l: launch(o, t, l), pattern_ctx=pctx)
-            observations, st_views, last = ts.observations, ts.st_views, ts.last
-            obs_ptr, traj_ptrs, last_ptrs = ts.obs_ptr, ts.traj_ptrs, ts.last_ptrs
-            self._pool_drain_waits()
-            self._traj_timed_launch(ts, lambda: launch(obs_ptr, traj_ptrs, last_ptrs), (OW + (S if want_states else 0)) * rows * B * isz)
-            return done(observations, st_views, last, N)
-        launch(obs_ptr, traj_ptrs, last_ptrs)
-        return done(observations, st_views, last, N)
+        self._placement.wait_stream(stream)
 
     def _traj_state(self, init_state, st_views, lead_shape, N):
         """Rebuild the State pytree of a trajectory: reference / PRNGKey broadcast along the saved rows,

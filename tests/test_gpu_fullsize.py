@@ -268,12 +268,13 @@ def _drift(name, env_name, chain):
     else:
         pairs = {"a": (k, chain["oracle64"])}
     out = {"config": name, "envs": int(k.shape[0]), "rows": int(k.shape[1]), "at_rows": [r for r in DRIFT_ROWS if r < k.shape[1]]}
-    for key, (x, y) in pairs.items():
-        d = _circ(env_name, np.abs(x.astype(np.float64) - y.astype(np.float64))).max(axis=2)  # [envs, rows]
-        run = np.maximum.accumulate(d, axis=1)
-        out[key] = {"max": [float(run[:, r].max()) for r in out["at_rows"]],
-                    "p99": [float(np.percentile(run[:, r], 99)) for r in out["at_rows"]],
-                    "p50": [float(np.percentile(run[:, r], 50)) for r in out["at_rows"]]}
+    for key, (x, y) in list(pairs.items()):
+        dd = _circ(env_name, np.abs(x.astype(np.float64) - y.astype(np.float64)))
+        for name_, d in ((key, dd.max(axis=2)), (key + "_rel", (dd / np.maximum(1.0, np.abs(y.astype(np.float64)))).max(axis=2))):  # [envs, rows]
+            run = np.maximum.accumulate(d, axis=1)
+            out[name_] = {"max": [float(run[:, r].max()) for r in out["at_rows"]],
+                          "p99": [float(np.percentile(run[:, r], 99)) for r in out["at_rows"]],
+                          "p50": [float(np.percentile(run[:, r], 50)) for r in out["at_rows"]]}
     try:
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(d, exist_ok=True)
@@ -320,21 +321,29 @@ def test_full_length_pmsm_tsit5_fp32_10000_steps():
     _assert_drift(dr, C3_BOUNDS)
 
 
-# Bounds on the chained full-horizon curves (units: full scale of each normalised observation). `a_max` bounds curve a at the last
-# row (kernel vs same-precision oracle), `a_over_c` bounds a relative to the fp32 floor c where the dynamics amplify rounding.
-C3_BOUNDS = None
-C2_BOUNDS = None
+# Bounds on the chained full-horizon curves (units: full scale of each normalised observation, angles on the circle; `rel` = the same
+# difference over max(1, |oracle|): PMSM's random-voltage trajectories leave the normalisation box by a factor of up to 38).
+# Measured in round 5 (256 environments, one MI355X; DESIGN.md §5 has the table):
+#   C3 PMSM Euler fp32, 10 000 chained steps: a (kernel vs fp32 oracle) max 5.0e-5 = 1.3e-6 relative, median environment 7.6e-6;
+#      c (fp32 oracle vs fp64 oracle, the floor of ANY fp32 implementation) max 4.3e-3, median 7.6e-4 -> the kernel's own share of the
+#      distance to the fp64 reference arithmetic is 1 %. PMSM Tsit5: a 3.2e-5, c 3.3e-3.
+#   C2 pendulum Euler fp32 (tau = 2e-2, random torque, no damping: chaotic): a <= 1.9e-6 over the first 100 rows, then a and c both
+#      grow to O(1) on the same curve (median environment at row 10 000: a 1.6e-2, c 2.2e-2) — no fp32 implementation can hold a fixed
+#      bound there, so the assertion is that the kernel stays BELOW the fp32 floor's curve.
+C3_BOUNDS = {"a_max": 1e-4, "a_rel_max": 1e-5, "a_over_c_last": 0.05}
+C2_BOUNDS = {"a_first_100": 1e-5, "a_over_c_p50": 1.5, "a_over_c_p99": 1.5}
 
 
 def _assert_drift(dr, bounds):
-    if bounds is None:  # measuring run
-        print(dr)
-        return
     last = -1
     if "a_max" in bounds:
         assert dr["a"]["max"][last] <= bounds["a_max"], dr["a"]
-    if "b_max" in bounds:
-        assert dr["b"]["max"][last] <= bounds["b_max"], dr["b"]
+    if "a_rel_max" in bounds:
+        assert dr["a_rel"]["max"][last] <= bounds["a_rel_max"], dr["a_rel"]
+    if "a_over_c_last" in bounds:
+        assert dr["a"]["max"][last] <= bounds["a_over_c_last"] * dr["c"]["max"][last], (dr["a"]["max"], dr["c"]["max"])
+    if "a_first_100" in bounds:
+        assert dr["a"]["max"][dr["at_rows"].index(100)] <= bounds["a_first_100"], dr["a"]
     for q in ("max", "p99", "p50"):
         if f"a_over_c_{q}" in bounds:
             for i, r in enumerate(dr["at_rows"]):

@@ -556,8 +556,8 @@ def test_gym_trajectories_with_a_misaligned_array_take_the_general_kernel(which)
         trunc = torch.zeros((K + 1, 3, B), dtype=torch.bool, device=dev)
         control = _native.make_control([0], [ref])
         _native.sim_ahead(env.ENV_ID, env._solver.id, torch.float32, B, K, 1, props, control, env.tau, env.tau, st_in, acts,
-                          _native.LAYOUT_LANE_MAJOR, obs, straj, _native.LAYOUT_LANE_MAJOR, last, _native.SEM_AHEAD, None, None,
-                          (rew, term, trunc))
+                          _native.LAYOUT_LANE_MAJOR, obs, straj, _native.LAYOUT_LANE_MAJOR, last, _native.SEM_AHEAD, None,
+                          _native.launch_opts(envs_per_lane=4), (rew, term, trunc))  # the widest form asked for explicitly
         torch.cuda.synchronize()
         assert _native.last_launch() == ("sim_ahead_kernel (general)" if off else "sim_ahead_kernel (lean, gym outputs)")
         results.append(dict(acts=acts, obs=obs.clone(), straj=[s.clone() for s in straj], rew=rew, term=term, trunc=trunc))

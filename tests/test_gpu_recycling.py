@@ -24,7 +24,7 @@ def _env(name="PMSM"):
 
 
 def _pool_size(env):
-    return env._slots_per_alloc(False)
+    return env._step_pool.per_alloc(False)
 
 
 def test_plain_loop_runs_on_recycled_tensors_and_matches_a_loop_that_keeps_everything():
@@ -192,7 +192,7 @@ def test_recycling_fuzz_against_a_run_that_never_recycles():
 
     env, s, acts = _env("CART_POLE")
     twin, s2, _ = _env("CART_POLE")
-    twin._slot_is_free = lambda *a, **k: False  # every pool is used once
+    twin._step_pool.is_free = lambda *a, **k: False  # every pool is used once
     rnd = random.Random(1234)
     held = {}  # step -> (expiry, kind, object)
     truth = {}
@@ -252,18 +252,20 @@ def test_slot_recycling_really_engages_on_this_torch_build(gym):
     the 11 -> 7 us host time is gone). This asserts that, in the plain loop, slots ARE handed out again on this build."""
     from exciting_environments_amd.core_env import CoreEnvironment
 
-    assert CoreEnvironment._storage_use_count is not None and CoreEnvironment._tensor_use_count is not None
+    from exciting_environments_amd import _placement
+
+    assert _placement.liveness_available()
     env = EnvironmentRegistry.PENDULUM.make(batch_size=1024, device="cuda:0")
     _, state = env.vmap_reset()
     act = torch.zeros((1024, 1), device=env.device)
     step = env.vmap_gym_step if gym else env.vmap_step
-    n = env._slots_per_alloc(gym)
+    n = env._step_pool.per_alloc(gym)
     ptrs, pools = [], set()
     for _ in range(4 * n + 3):
         out = step(state, act)
         state = out[-1]
         ptrs.append(out[0].data_ptr())
-        pools.add(id(env._slots[gym]))
+        pools.add(id(env._step_pool.slots[gym]))
         del out
     assert len(pools) == 1, "a new pool was allocated although every earlier output was dead"
     assert len(set(ptrs)) == n and ptrs[:n] == ptrs[n:2 * n] == ptrs[2 * n:3 * n]

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def _env(env_name="pmsm", B=4096, dtype=torch.float32, pool=True, placed=True):
     env, props, keep, spec = make_env(env_name, B, dtype)
     env._SHARED_TRAJ_BYTES = 0  # test sizes through the path of the large outputs
-    env._PLACED_TRAJ_BYTES = 0 if placed else (1 << 62)
+    env._placement.PLACED_BYTES = 0 if placed else (1 << 62)
     env.trajectory_pool = pool
     st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=5)
     return env, to_state(env, st)
@@ -53,7 +53,7 @@ def test_chained_run_alternates_between_two_sets_and_equals_the_unpooled_run(env
         ptrs.append(obs.data_ptr())
         del obs, states
     assert len(set(ptrs)) == 2 and ptrs[0] == ptrs[2] == ptrs[4] and ptrs[1] == ptrs[3] == ptrs[5]
-    assert len(env._traj_sets) == 2
+    assert len(env._placement.sets) == 2
     lp = env.last_placement  # lane-major actions: judged by the access pattern against the fill rate (round 4), else by launch times
     assert lp is not None and len(lp.get("candidate_pattern_over_fill") or lp.get("candidate_ms")) >= 1
 
@@ -115,7 +115,7 @@ def test_a_set_is_not_reused_from_another_stream_and_inputs_are_never_written():
     for x, y in zip(_leaves(env, s0), before):
         assert torch.equal(x, y)
     env.release_trajectory_buffers()
-    assert env._traj_sets == []
+    assert env._placement.sets == []
 
 
 def test_last_state_of_a_pooled_set_feeds_the_next_call_without_aliasing():
@@ -168,7 +168,7 @@ def test_placement_search_logic_with_scripted_timings():
     at least two candidates and stops at a 7 % contrast; a later set stops at the first candidate within 2 % of the best time
     known; without contrast all tries are used and the fastest wins; rejected blocks are released."""
     env, _ = _env("pmsm", B=1024)
-    env._PLACEMENT_SPACER_BYTES = 1 << 20
+    env._placement.SPACER_BYTES = 1 << 20
     B, rows, OW, S, isz = 1024, 9, 8, 7, 4
 
     def run(times):
@@ -179,19 +179,19 @@ def test_placement_search_logic_with_scripted_timings():
             return next(it)
 
         obs_buf = torch.empty((rows, OW, B), dtype=torch.float32, device=env.device)
-        block, diag = env._place_state_block(obs_buf, B, rows, OW, S, isz, fake)
+        block, diag = env._placement.place_state_block(obs_buf, B, rows, OW, S, isz, fake)
         return block, diag, seen
 
-    env._placement_best.clear()
+    env._placement.best.clear()
     block, diag, seen = run([5.4, 4.9, 9.9, 9.9])          # contrast after two candidates: stop, keep the second
     assert diag["candidate_ms"] == [5.4, 4.9] and diag["chosen"] == 1 and block.data_ptr() == seen[1]
-    assert env._placement_best[(B, rows, OW, S)] == 4.9
+    assert env._placement.best[(B, rows, OW, S)] == 4.9
     block, diag, seen = run([4.95, 9.9])                   # a later set: within 2 % of the best known -> first candidate
     assert diag["candidate_ms"] == [4.95] and diag["best_known_ms_before"] == 4.9
     block, diag, seen = run([5.3, 5.35, 5.1, 5.2, 5.25, 5.4])  # never matches 4.9: all six tries of a small block, the fastest kept
     assert len(diag["candidate_ms"]) == 6 and diag["chosen"] == 2 and block.data_ptr() == seen[2]
     assert len(set(seen)) == 6                             # six distinct blocks were alive at the same time
-    env._placement_best.clear()
+    env._placement.best.clear()
     block, diag, seen = run([5.0, 5.05, 5.02, 4.98, 5.01, 5.03])  # first set, no contrast: all tries, fastest kept
     assert len(diag["candidate_ms"]) == 6 and diag["chosen"] == 3
     env.trajectory_placement = "off"
@@ -207,7 +207,7 @@ def test_env_major_sets_are_pooled_and_equal_the_unpooled_run(env_name):
     env, s0 = _env(env_name, B=B)
     ref_env, r0 = _env(env_name, B=B, pool=False, placed=False)
     env.traj_layout = ref_env.traj_layout = "env_major"
-    ref_env._PLACED_TRAJ_BYTES = 1 << 62  # the plain path of the small env-major outputs
+    ref_env._placement.PLACED_BYTES = 1 << 62  # the plain path of the small env-major outputs
     g = torch.Generator(device=env.device)
     ptrs, state, rstate = [], s0, r0
     for i in range(6):
@@ -238,7 +238,7 @@ def test_unpooled_sets_are_not_probed():
     a = _actions(env, 8, 11)
     o1 = env.vmap_sim_ahead(s0, a, env.tau, env.tau)[0]
     o2 = env.vmap_sim_ahead(s0, a, env.tau, env.tau)[0]
-    assert env.last_placement is None and env._traj_sets == []
+    assert env.last_placement is None and env._placement.sets == []
     assert o1.data_ptr() != o2.data_ptr() and torch.equal(o1, o2)
 
 
@@ -268,10 +268,14 @@ def test_pool_wait_stream_orders_the_reuse_behind_a_foreign_reader():
 
 
 def test_placement_settles_and_reports_real_launch_times():
-    """The pooled sets are compared by HIP-event times of their real launches; `trajectory_placement_settled` turns True once
-    every pooled set of the shape has one (and no replacement is pending)."""
+    """Sets the absolute criterion cannot judge (here: row-major actions) are compared by HIP-event times of their REAL launches —
+    the first launch into a set is recorded apart and never a judgement; `trajectory_placement_settled` turns True once every pooled
+    set of the shape has a steady time and none is up for replacement. Sets accepted by the absolute criterion are final at once."""
     env, st = _env("pendulum", B=1 << 14)
-    acts = _actions(env, 32, 70)
+    K = 32
+    g = torch.Generator(device=env.device)
+    g.manual_seed(70)
+    acts = torch.rand((env.batch_size, K, 1), generator=g, device=env.device) * 2 - 1  # row-major: no pattern replay
     assert env.trajectory_placement_settled  # nothing pooled yet
     out = env.vmap_sim_ahead(st, acts, env.tau, env.tau)
     seen = [env.trajectory_placement_settled]
@@ -280,21 +284,32 @@ def test_placement_settles_and_reports_real_launch_times():
         torch.cuda.synchronize()
         seen.append(env.trajectory_placement_settled)
     assert seen[0] is False and seen[-1] is True
-    assert len(env._traj_sets) == 2 and all(t.steady_ms is not None and t.steady_ms > 0 for t in env._traj_sets)
+    sets = env._placement.sets
+    assert len(sets) == 2 and all(t.first_ms is not None and t.steady_ms is not None and t.steady_ms > 0 for t in sets)
     env.trajectory_placement = "off"
     assert env.trajectory_placement_settled
+    # lane-major actions: judged by the pattern -> settled as soon as both sets of the shape exist
+    env2, st2 = _env("pendulum", B=1 << 14)
+    env2._placement.PATTERN_ACCEPT = 0.0  # test-sized sets: whatever the pattern says is accepted
+    a2 = _actions(env2, K, 71)
+    o = env2.vmap_sim_ahead(st2, a2, env2.tau, env2.tau)
+    o = env2.vmap_sim_ahead(o[2], a2, env2.tau, env2.tau)
+    assert len(env2._placement.sets) == 2 and all(t.judged_by_pattern for t in env2._placement.sets)
+    assert env2.trajectory_placement_settled
 
 
-def test_arena_pair_is_made_once_reused_and_equals_the_unpooled_run():
-    """Round 4: the first two sets of a shape are views of ONE arena [obs A | obs B | gap | states A | states B] — no probe
-    launches. The chained run alternates between them, holds the bits of the unpooled run, never writes a set somebody still
-    sees, and a caller that holds on to outputs gets searched single sets from the third call on (no second arena)."""
+def test_ordered_pair_is_made_once_reused_and_equals_the_unpooled_run():
+    """The first two sets of a shape are four allocations made in the order obs A, obs B, states A, states B — no probe launches of
+    the kernel. The chained run alternates between them, holds the bits of the unpooled run, never writes a set somebody still
+    sees; holding ONE returned array keeps only that array's allocation busy (round 4's single arena kept both sets busy for
+    ever); a caller that holds on to outputs gets searched single sets from the third call on (no second pair)."""
     env, st = _env("pmsm", B=2048)
-    env._ARENA_MIN_SET_BYTES, env._ARENA_MIN_DISTANCE, env._PATTERN_ACCEPT = 0, 0, 0.0  # test-sized sets: accept whatever the pattern says
+    pl = env._placement
+    pl.QUAD_MIN_SET_BYTES, pl.QUAD_MIN_DISTANCE, pl.PATTERN_ACCEPT = 0, 0, 0.0  # test-sized sets: accept whatever the pattern says
     ref_env, ref_st = _env("pmsm", B=2048, pool=False)
     K = 12
     acts = [_actions(env, K, 80 + i) for i in range(5)]
-    ptrs, outs = [], []
+    ptrs = []
     s, rs = st, ref_st
     for i in range(5):
         o, states, s = env.vmap_sim_ahead(s, acts[i], env.tau, env.tau)
@@ -302,23 +317,37 @@ def test_arena_pair_is_made_once_reused_and_equals_the_unpooled_run():
         assert torch.equal(o, ro) and torch.equal(states.physical_state.i_q, rstates.physical_state.i_q)
         ptrs.append(o.data_ptr())
         if i == 0:
-            assert env.last_placement["what"].startswith("one arena") and len(env._traj_sets) == 2
-            a0, a1 = env._traj_sets[0], env._traj_sets[1]
-            assert a0.obs_buf.untyped_storage().data_ptr() == a1.obs_buf.untyped_storage().data_ptr()  # one allocation
-            for t in (a0, a1):  # observations of both sets first, then the state blocks: each set's streams start apart
-                assert t.st_buf.data_ptr() - t.obs_buf.data_ptr() >= min(2 * a0.obs_buf.numel(), a0.obs_buf.numel() + a0.st_buf.numel()) * 4
+            assert env.last_placement["what"].startswith("four allocations") and len(pl.sets) == 2
+            a0, a1 = pl.sets[0], pl.sets[1]
+            stor = {t.untyped_storage().data_ptr() for t in (a0.obs_buf, a1.obs_buf, a0.st_buf, a1.st_buf)}
+            assert len(stor) == 4  # an allocation each
         del o, states
     assert ptrs[0] == ptrs[2] == ptrs[4] and ptrs[1] == ptrs[3] and ptrs[0] != ptrs[1]
-    # a caller that keeps every output: the pair is used up after two calls, then single sets (no second arena)
+    # a kept view of set A's observations pins set A only: set B keeps coming round
+    held = env.vmap_sim_ahead(s, acts[0], env.tau, env.tau)
+    view = held[0][:, -1]
+    pa = held[0].data_ptr()
+    s = held[2]
+    del held
+    seen = set()
+    for i in range(4):
+        o, _, s = env.vmap_sim_ahead(s, acts[i], env.tau, env.tau)
+        assert o.data_ptr() != pa
+        seen.add(o.data_ptr())
+        del o
+    assert len(seen) == 2  # set B and ONE further single set alternate: no third, fourth ... set is made
+    del view
+    # a caller that keeps every output: the pair is used up after two calls, then single sets (no second pair)
     env2, st2 = _env("pmsm", B=2048)
-    env2._ARENA_MIN_SET_BYTES, env2._ARENA_MIN_DISTANCE, env2._PATTERN_ACCEPT = 0, 0, 0.0
+    p2 = env2._placement
+    p2.QUAD_MIN_SET_BYTES, p2.QUAD_MIN_DISTANCE, p2.PATTERN_ACCEPT = 0, 0, 0.0
     held, s2 = [], st2
     for i in range(4):
         out = env2.vmap_sim_ahead(s2, acts[i], env2.tau, env2.tau)
         held.append(out)
         s2 = out[2]
-    stor = {o[0].untyped_storage().data_ptr() for o in held}
-    assert len(stor) == 3  # calls 1 and 2 share the arena, calls 3 and 4 have allocations of their own
+    assert len({o[0].untyped_storage().data_ptr() for o in held}) == 4
+    assert p2.last is not None and "four allocations" not in (p2.last.get("what") or "")
     torch.cuda.synchronize()
     s3 = st
     for i in range(4):  # and what they hold is still what the unpooled run computes
@@ -327,11 +356,11 @@ def test_arena_pair_is_made_once_reused_and_equals_the_unpooled_run():
 
 
 def test_pattern_judged_placement_accepts_on_the_absolute_criterion():
-    """The absolute placement criterion (pattern rate / fill rate >= _PATTERN_ACCEPT) with a scripted score: the search stops at
+    """The absolute placement criterion (pattern rate / fill rate >= PATTERN_ACCEPT) with a scripted score: the search stops at
     the first candidate that meets it, walks on while none does (keeping rejected blocks alive) and then keeps the best one."""
     env, _ = _env("pmsm", B=1024)
-    env._PLACEMENT_SPACER_BYTES = 1 << 20
-    env._fill_gbs = 6800.0
+    env._placement.SPACER_BYTES = 1 << 20
+    env._placement.fill_gbs = 6800.0
     B, rows, OW, S, isz = 1024, 12, 8, 7, 4
 
     def run(scores):
@@ -342,7 +371,7 @@ def test_pattern_judged_placement_accepts_on_the_absolute_criterion():
             return next(it)
 
         obs_buf = torch.empty((rows, OW, B), dtype=torch.float32, device=env.device)
-        block, diag = env._place_state_block(obs_buf, B, rows, OW, S, isz, None, pattern=fake)
+        block, diag = env._placement.place_state_block(obs_buf, B, rows, OW, S, isz, None, pattern=fake)
         return block, diag, seen
 
     block, diag, seen = run([(5.4, 0.76), (5.0, 0.83), (9.9, 0.9)])

@@ -22,6 +22,6 @@ for it in range(40):
     out = env.vmap_sim_ahead(st, acts, env.tau, env.tau)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3
-    sets = [(t.uses, None if t.steady_ms is None else round(t.steady_ms, 3)) for t in env._traj_sets]
-    print(f"call {it:2d} {ms:8.2f} ms settled={env.trajectory_placement_settled} sets={sets} replaced={dict(env._placement_replaced)} "
+    sets = [(t.uses, None if t.steady_ms is None else round(t.steady_ms, 3)) for t in env._placement.sets]
+    print(f"call {it:2d} {ms:8.2f} ms settled={env.trajectory_placement_settled} sets={sets} replaced={dict(env._placement.replaced)} "
           f"placement={ {k: v for k, v in (env.last_placement or {}).items() if k in ('pattern_over_fill', 'chosen_ms', 'arena_rejected')} }", flush=True)

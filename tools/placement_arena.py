@@ -64,4 +64,4 @@ for it in range(40):
     torch.cuda.synchronize()
     if it >= 7 and env.trajectory_placement_settled:
         break
-print("library (searched, pooled):", [None if t.steady_ms is None else round(t.steady_ms, 3) for t in env._traj_sets], flush=True)
+print("library (searched, pooled):", [None if t.steady_ms is None else round(t.steady_ms, 3) for t in env._placement.sets], flush=True)
