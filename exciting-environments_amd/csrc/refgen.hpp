@@ -75,6 +75,18 @@ __device__ __forceinline__ int64_t rng_randint(Key key, int32_t lo, int32_t hi) 
   return (int64_t)lo + (int64_t)off;
 }
 
+// the same under jax_enable_x64 (int64 form: two 64-bit draws, uint64 wrap-around arithmetic) — what the reference draws when its
+// arrays are float64 (x64 is the only way to get them, and it makes int64 the default int type); T selects the form
+__device__ __forceinline__ int64_t rng_randint64(Key key, int64_t lo, int64_t hi) {
+  const uint64_t higher = rng_bits64(rng_split(key, 0), 0), lower = rng_bits64(rng_split(key, 1), 0);
+  uint64_t span = (uint64_t)hi - (uint64_t)lo;
+  if (hi <= lo) span = 1u;
+  uint64_t mult = ((uint64_t)1 << 32) % span;
+  mult = (mult * mult) % span;
+  const uint64_t off = ((higher % span) * mult + (lower % span)) % span;
+  return (int64_t)((uint64_t)lo + off);
+}
+
 __device__ __forceinline__ float xerfinv(float x) { return ::erfinvf(x); }
 __device__ __forceinline__ double xerfinv(double x) { return ::erfinv(x); }
 __device__ __forceinline__ float xlog(float x) { return ::logf(x); }
@@ -218,7 +230,7 @@ template <class M, typename T> __global__ void __launch_bounds__(BLOCK) update_r
       }
     }
     const Key k_new = rng_split(leaf, 0), sub = rng_split(leaf, 1);
-    h = rng_randint(sub, ka.hold_min, ka.hold_max);
+    h = (sizeof(T) == 8) ? rng_randint64(sub, ka.hold_min, ka.hold_max) : rng_randint(sub, ka.hold_min, ka.hold_max);
     ka.keys[2 * i] = (int64_t)k_new.k0;
     ka.keys[2 * i + 1] = (int64_t)k_new.k1;
   } else if (copy) {

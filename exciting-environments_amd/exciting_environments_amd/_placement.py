@@ -161,9 +161,9 @@ class StepSlotPool:
 # at a time — observations and state leaves allocated back to back by a fresh process — runs at ~5.0 TB/s where the same kernel over
 # buffers in two regions runs at ~5.9 TB/s; a plain sequential fill shows the same two levels, so this is the platform, not the
 # kernel. Virtual addresses say nothing about the region, so a new set of output buffers is placed by MEASUREMENT and then pooled:
-#   * the first two sets of a shape are four allocations made in the order [observations A, observations B, states A, states B]
-#     (the other set's observations are the distance between a set's two kinds of write streams), judged by the absolute criterion
-#     below; no probe launches of the trajectory kernel, no spacers;
+#   * the first two sets of a shape are one arena [observations A | observations B | states A | states B] (the other set's
+#     observations are the distance between a set's two kinds of write streams), judged by the absolute criterion below; no probe
+#     launches of the trajectory kernel, no spacers;
 #   * otherwise a SEARCH: candidate state blocks are judged one after the other while the rejected blocks and a spacer (hipMalloc
 #     outside torch's cache) stay allocated, so that the next candidate lands a region further on;
 #   * the judge is ABSOLUTE where the launch's access pattern can be replayed without arithmetic (excenv_stream_pattern over the
@@ -209,9 +209,9 @@ class TrajectoryPlacement:
     DECIDE_USES = 3               # ... while it has at most this many steady timings: afterwards it stays (no search in a long run)
     SPACER_BYTES = 16 << 30       # a rejected block + this much memory stay allocated while the next block is made
     PATTERN_ACCEPT = 0.81         # absolute judge: pattern rate / fill rate
-    QUAD_MIN_DISTANCE = 17 << 30  # ordered allocations: observations -> states of one set at least this far apart
+    QUAD_MIN_DISTANCE = 17 << 30  # arena pair: observations -> states of one set at least this far apart
     QUAD_MIN_SET_BYTES = 4 << 30  # smaller sets keep the search (an artificial gap measured 0.57 for C2)
-    QUAD_ENV_MAJOR = os.environ.get("EXCENV_EM_ARENA", "1") != "0"  # row-major (reference-shaped) sets take the ordered form too
+    QUAD_ENV_MAJOR = os.environ.get("EXCENV_EM_ARENA", "1") != "0"  # row-major (reference-shaped) sets take the arena too
 
     def __init__(self, env):
         self.env = env
@@ -595,54 +595,56 @@ class TrajectoryPlacement:
             self.sets.append(ts)
         return ts
 
-    # Deterministic placement of the FIRST two sets of a shape: four allocations made in the order
-    #     observations A, observations B, state block A, state block B
+    # Deterministic placement of the FIRST two sets of a shape (round 4): one arena laid out
+    #     [observations A | observations B | state block A | state block B]
     # so that a launch's two kinds of write streams — 8 observation components, 7 state leaves for PMSM — start at least
-    # QUAD_MIN_DISTANCE apart (the other set's observations are the distance), which is what turned the slow placement level into
-    # the fast one in every experiment of profiles/r03_placement_regions.md. Round 4 made ONE allocation of the four parts
-    # (tools/placement_arena.py: 0.709 / 0.716 of the roof for the two sets of the headline launch, as good as the search, with no
-    # probe launches); its price was that holding a single returned tensor kept all 51 GB alive and made BOTH sets look busy for
-    # ever. Four allocations in the same order land the same way in a fresh process (the driver hands out consecutive
-    # ranges), each returned array pins only its own allocation, and the absolute criterion still judges the result: a pair that
-    # is not in the fast level goes back and the search takes over.
+    # QUAD_MIN_DISTANCE apart inside one allocation (the other set's observations are the distance), which is what turned the slow
+    # placement level into the fast one in every experiment of profiles/r03_placement_regions.md. tools/placement_arena.py: 0.709 /
+    # 0.716 of the roof for the two sets of the headline launch, as good as the search, with no probe launches of the kernel, no
+    # spacers, and the two sets run alike (driver, round 4: 4.884 / 4.887 ms). Round 5 tried FOUR allocations in the same order
+    # instead (so that a kept view would pin one array, not the arena): the driver does not place consecutive allocations like one
+    # block — the pair failed the absolute criterion, the search took over and the two sets ran 3 % apart (5.03 / 4.89 ms, bench
+    # 0.718): one allocation it stays. Its price: both sets are views of one storage — a foreign alias of ANY returned array (a kept
+    # view, `detach()`, DLPack) makes both sets look busy, the calls that follow make single searched sets (at most POOL_SETS of them
+    # stay pooled), and the arena's memory returns when the alias dies (`trajectory_placement = "search"` restores one allocation per
+    # returned array). The plain chain `obs, states, state = env.vmap_sim_ahead(state, ...)` alternates between the two sets.
     def _ordered_pair(self, key, B, rows, OW, S, last_e, isz, stream, env_major=False, pattern_ctx=None):
         env = self.env
         dt, dev = env.dtype, env.device
+        up = lambda n: (n + 63) // 64 * 64  # every sub-buffer starts on a 256-byte boundary
         leaf_e = (rows * B * isz + 127) // 128 * 128 // isz if env_major else rows * B
-        obs_b, blk_b = rows * OW * B * isz, S * leaf_e * isz
-        if min(2 * obs_b, obs_b + blk_b) < self.QUAD_MIN_DISTANCE:
-            return None  # the other set's observations are not enough distance: search
-        if 2 * (obs_b + blk_b) > torch.cuda.mem_get_info(dev)[0] * 0.8:
+        obs_e, blk_e = up(rows * OW * B), up(S * leaf_e)
+        if min(2 * obs_e, obs_e + blk_e) * isz < self.QUAD_MIN_DISTANCE:
+            return None  # the other set's observations are not enough distance (an artificial gap measured 0.57 for C2): search
+        total = 2 * obs_e + 2 * blk_e
+        if total * isz > torch.cuda.mem_get_info(dev)[0] * 0.8:
             return None  # not worth crowding the device: the searched single sets take over
-        obs_shape = (B, rows, OW) if env_major else (rows, OW, B)
-        blk_shape = (S, leaf_e) if env_major else (S, rows, B)
         try:
-            obs = [torch.empty(obs_shape, dtype=dt, device=dev) for _ in range(2)]
-            blk = [torch.empty(blk_shape, dtype=dt, device=dev) for _ in range(2)]
+            arena = torch.empty(total, dtype=dt, device=dev)
         except torch.OutOfMemoryError:
             return None
         self.quad_made.add(key)
         sets = []
         for k in range(2):
             ts = TrajSet(key)
-            ts.obs_buf, ts.st_buf = obs[k], blk[k]
+            ts.obs_buf = arena[k * obs_e: k * obs_e + rows * OW * B].view((B, rows, OW) if env_major else (rows, OW, B))
+            b0 = 2 * obs_e + k * blk_e
+            ts.st_buf = arena[b0: b0 + S * leaf_e].view((S, leaf_e) if env_major else (S, rows, B))
             ts.lbuf = torch.empty((S, last_e), dtype=dt, device=dev)
-            d = abs(blk[k].data_ptr() - obs[k].data_ptr())
-            ts.placement = {"ordered_pair_gib": round(2 * (obs_b + blk_b) / 2**30, 2), "set": k,
-                            "virtual_distance_gib": round(d / 2**30, 2),
-                            "what": "four allocations in the order obs A, obs B, states A, states B: no probe launches of the kernel"}
+            ts.placement = {"arena_gib": round(total * isz / 2**30, 2), "set": k,
+                            "what": "one arena [obs A | obs B | states A | states B]: no probe launches of the kernel"}
             self._finish_views(ts, B, rows, S, leaf_e, last_e, isz, env_major, True)
             sets.append(ts)
-        del obs, blk
+        del arena
         if pattern_ctx is not None and not env_major and (B * isz) % 16 == 0 and rows >= 10:
-            # both sets must be in the fast level by the absolute criterion, else they go back and the sets are searched
+            # both sets must be in the fast level by the absolute criterion, else the arena goes back and the sets are searched
             for ts in sets:
                 ms, ratio = self.pattern_score(ts.obs_buf, ts.st_buf.data_ptr(), leaf_e, B, rows, OW, S, isz, *pattern_ctx)
                 ts.placement["pattern_over_fill"] = round(ratio, 4)
                 ts.placement["pattern_ms"] = round(ms, 4)
                 ts.placement["accept_at"] = self.PATTERN_ACCEPT
             if min(t.placement["pattern_over_fill"] for t in sets) < self.PATTERN_ACCEPT:
-                self.last = {"ordered_pair_rejected": [t.placement["pattern_over_fill"] for t in sets], "accept_at": self.PATTERN_ACCEPT}
+                self.last = {"arena_rejected": [t.placement["pattern_over_fill"] for t in sets], "accept_at": self.PATTERN_ACCEPT}
                 del sets, ts
                 torch.cuda.empty_cache()
                 return None

@@ -186,7 +186,7 @@ class GymWrapper:
         if self._ref_rng is None and _random.is_key(state.PRNGKey):
             init = env.vmap_init_state(state.PRNGKey)
             sp = _random.split(init.PRNGKey)
-            new_hold = _random.randint(sp[:, 1, :], 1, lo, hi).to(hold_steps.dtype)
+            new_hold = _random.randint(sp[:, 1, :], 1, lo, hi, x64=env.dtype is torch.float64).to(hold_steps.dtype)  # x64 <=> float64 arrays
             state = replace(state, PRNGKey=torch.where(mask, sp[:, 0, :], state.PRNGKey.to(sp.device)))
         else:
             init = env.vmap_init_state(self._ref_rng)

@@ -100,12 +100,31 @@ def _u32(x):
     return x & _M32
 
 
-def randint(key: torch.Tensor, n: int, minval: int, maxval: int) -> torch.Tensor:
-    """jax.random.randint(key, (n,), minval, maxval) with the default int32 dtype for every key of a [..., 2] batch ->
-    int64 tensor [..., n]. Two 32-bit draws (higher / lower bits from split(key)) reduce the modulo bias; all arithmetic is
-    uint32 with wrap-around, as in the source."""
+def _umod64(x: torch.Tensor, span: int) -> torch.Tensor:
+    """x mod span for uint64 bit patterns held in int64 tensors (torch has no uint64 arithmetic): a negative int64 s stands for
+    s + 2**64, so its residue is (s mod span + 2**64 mod span) mod span."""
+    r = torch.remainder(x, span)
+    return torch.where(x < 0, torch.remainder(r + ((1 << 64) % span), span), r)
+
+
+def randint(key: torch.Tensor, n: int, minval: int, maxval: int, x64: bool = False) -> torch.Tensor:
+    """jax.random.randint(key, (n,), minval, maxval) for every key of a [..., 2] batch -> int64 tensor [..., n]. Two draws
+    (higher / lower bits from split(key)) reduce the modulo bias (jax/_src/random.py _randint).
+    x64=False: the default int32 dtype — 32-bit draws, uint32 wrap-around arithmetic.
+    x64=True: what the same call returns under jax_enable_x64 (the reference's tests run that way; gym_wrapper.py:183-188 passes no
+    dtype, so the default int type is int64) — 64-bit draws, uint64 arithmetic. Spans below 2**31 (hold-step ranges); parity of
+    this form is unpinned (no published value), it is checked against a big-integer restatement in tests/test_oracle_rng.py."""
     minval, maxval = int(minval), int(maxval)
     ks = split(key)
+    if x64:
+        span = (maxval - minval) if maxval > minval else 1
+        if span >= (1 << 31):
+            raise NotImplementedError("randint(x64=True): span must be below 2**31")
+        higher, lower = random_bits(ks[..., 0, :], n, 64), random_bits(ks[..., 1, :], n, 64)
+        multiplier = (1 << 32) % span
+        multiplier = (multiplier * multiplier) % span
+        off = torch.remainder(_umod64(higher, span) * multiplier + _umod64(lower, span), span)  # < span**2 + span < 2**63: no wrap
+        return off + minval
     higher, lower = random_bits(ks[..., 0, :], n, 32), random_bits(ks[..., 1, :], n, 32)
     span = (maxval - minval) & _M32
     if maxval <= minval:

@@ -269,10 +269,14 @@ int excenv_state_from_observation(int env, int dtype, int64_t B, const excenv_pr
 /* ---- replaces GymWrapper.update_ref / generate_new_ref (gym_wrapper.py:170-192), one thread per environment: where
  * hold[i] == 0 draw a random initial state from the environment's key (init_state(rng), e.g. pendulum_env.py:270-276, PMSM
  * pmsm_env.py:402-456 incl. jax.random.ball), copy its controlled fields into reference[j][i], split the key for the new hold
- * time (jax.random.randint(sub, (1,), hold_steps_min, hold_steps_max), int32 form) and keep the other half as the new key;
- * then hold[i] -= 1. All arrays are updated in place. keys: [B][2] uint32 key words stored in int64 (jax.random key data);
- * the samplers restate JAX's published algorithms (threefry2x32 split / bits / uniform / randint / normal / gamma / ball) —
- * parity with JAX itself is unpinned. */
+ * time (jax.random.randint(sub, (1,), hold_steps_min, hold_steps_max) in the default int type: the int32 form for EXCENV_F32, the
+ * int64 form JAX draws under jax_enable_x64 for EXCENV_F64 — float64 arrays exist in the reference only with x64 on) and keep the
+ * other half as the new key; then hold[i] -= 1. All arrays are updated in place. keys: [B][2] uint32 key words stored in int64
+ * (jax.random key data). The samplers restate JAX's published algorithms (threefry2x32 split / bits / uniform / randint / normal /
+ * gamma / ball); the CPU oracle's restatement of the same functions is pinned on the Random123 known-answer vectors and on the
+ * jax.random.split / normal values printed in JAX's documentation (tests/test_oracle_rng.py), and these kernels are compared
+ * with that oracle (tests/test_gpu_rng_oracle.py). Unpinned: the x64 form of randint (no published value; checked against a
+ * big-integer restatement). */
 int excenv_update_ref(int env, int dtype, int64_t B, const excenv_props_t* props, int32_t n_control,
                       const int32_t* control_idx, void* const* reference, int64_t* keys, int64_t* hold,
                       int32_t hold_steps_min, int32_t hold_steps_max, void* stream);

@@ -30,6 +30,7 @@ SOLVER_IDS = {"euler": 0, "rk4": 1, "tsit5": 2}
 DTYPE_IDS = {np.dtype(np.float32): 0, np.dtype(np.float64): 1}
 LAYOUT_ENV_MAJOR, LAYOUT_LANE_MAJOR = 0, 1
 SEM_STEP, SEM_AHEAD = 0, 1
+SEM_AHEAD_ACCUMULATED_T = 2  # oracle-only experiment: diffrax's accumulated stage times decide the action index (oracle_body.inc)
 
 # (S, A, O, P) and field orders, mirroring include/excenv.h
 ENV_DIMS = {0: (2, 1, 2, 3), 1: (2, 1, 2, 3), 2: (4, 1, 4, 6), 3: (4, 1, 4, 9), 4: (1, 1, 1, 4), 5: (7, 2, 8, 7)}
@@ -355,6 +356,16 @@ def randint(keys, m: int, minval: int, maxval: int) -> np.ndarray:
     out = np.empty((k.shape[0], m), dtype=np.int64)
     lib().oracle_randint(ctypes.c_int64(k.shape[0]), k.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(m), ctypes.c_int32(minval),
                          ctypes.c_int32(maxval), out.ctypes.data_as(ctypes.c_void_p))
+    return out.reshape(lead + (m,))
+
+
+def randint64(keys, m: int, minval: int, maxval: int) -> np.ndarray:
+    """jax.random.randint under jax_enable_x64 (int64 form, two 64-bit draws)."""
+    lead = np.asarray(keys).shape[:-1]
+    k = _keys(keys)
+    out = np.empty((k.shape[0], m), dtype=np.int64)
+    lib().oracle_randint64(ctypes.c_int64(k.shape[0]), k.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(m), ctypes.c_int64(minval),
+                           ctypes.c_int64(maxval), out.ctypes.data_as(ctypes.c_void_p))
     return out.reshape(lead + (m,))
 
 

@@ -108,6 +108,22 @@ static int32_t rng_randint_i32(const uint32_t key[2], uint32_t i, int32_t minval
   const uint32_t off = ((higher % span) * mult + (lower % span)) % span;
   return (int32_t)((uint32_t)minval + off);
 }
+/* The same function as JAX evaluates it with jax_enable_x64 (the reference's own tests run that way, tests/test_gym_wrapper.py;
+ * gym_wrapper.py:183-188 passes no dtype, so randint draws the default int type: int64): nbits = 64, two 64-bit draws, span /
+ * multiplier arithmetic in uint64 with wrap-around (jax/_src/random.py _randint). PARITY UNPINNED: no published x64 randint value
+ * is known to the author; tests/test_oracle_rng.py checks it against an independent big-integer restatement of the same source. */
+static int64_t rng_randint_i64(const uint32_t key[2], uint32_t i, int64_t minval, int64_t maxval) {
+  uint32_t k1[2], k2[2];
+  rng_split_i(key, 0, k1);
+  rng_split_i(key, 1, k2);
+  const uint64_t higher = rng_bits64(k1, i), lower = rng_bits64(k2, i);
+  uint64_t span = (uint64_t)maxval - (uint64_t)minval;
+  if (maxval <= minval) span = 1u;
+  uint64_t mult = ((uint64_t)1 << 32) % span; /* 2 ** (nbits / 2) % span */
+  mult = (mult * mult) % span;                /* == 2 ** nbits % span (uint64 product, wraps like lax.mul) */
+  const uint64_t off = ((higher % span) * mult + (lower % span)) % span;
+  return (int64_t)((uint64_t)minval + off);
+}
 /* erf_inv in double precision: Winitzki's closed-form start, then Newton on libm's erf (|y| < 0.5) or on erfc of the tail
  * (no cancellation in 1 - |y|: exact for |y| >= 0.5). */
 static double erfinv_d(double y) {
@@ -126,6 +142,9 @@ static double erfinv_d(double y) {
 }
 
 /* ---- float instantiation ---- */
+/* oracle-only semantics value (not part of include/excenv.h: the product offers EXCENV_SEM_STEP / EXCENV_SEM_AHEAD) */
+#define ORACLE_SEM_AHEAD_ACCUMULATED_T 2
+
 #define REAL float
 #define FN(x) CAT(x, _f32)
 #define R_SIN sinf
@@ -246,7 +265,7 @@ int oracle_sim_ahead(int env, int solver, int dtype, int64_t B, int64_t K, int32
   if (rc) return rc;
   if (K < 0 || substeps < 1) return EXCENV_EINVAL;
   if (env == EXCENV_PMSM && substeps != 1) return EXCENV_EUNSUPPORTED;
-  if (semantics != EXCENV_SEM_STEP && semantics != EXCENV_SEM_AHEAD) return EXCENV_EINVAL;
+  if (semantics != EXCENV_SEM_STEP && semantics != EXCENV_SEM_AHEAD && semantics != ORACLE_SEM_AHEAD_ACCUMULATED_T) return EXCENV_EINVAL;
   if (!props || !state_in || (!actions && K > 0) || !obs_traj || !last_state) return EXCENV_ENULL;
   if (control && control->n_control == 0) control = NULL;
   return dtype == EXCENV_F32
@@ -291,6 +310,14 @@ void oracle_randint(int64_t n, const int64_t* keys, int32_t m, int32_t minval, i
   for (int64_t i = 0; i < n; ++i) {
     const uint32_t key[2] = {(uint32_t)keys[2 * i], (uint32_t)keys[2 * i + 1]};
     for (int32_t j = 0; j < m; ++j) out[i * m + j] = (int64_t)rng_randint_i32(key, (uint32_t)j, minval, maxval);
+  }
+}
+
+/* out [n][m] = jax.random.randint(key, (m,), minval, maxval) under jax_enable_x64 (int64 form) */
+void oracle_randint64(int64_t n, const int64_t* keys, int32_t m, int64_t minval, int64_t maxval, int64_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t key[2] = {(uint32_t)keys[2 * i], (uint32_t)keys[2 * i + 1]};
+    for (int32_t j = 0; j < m; ++j) out[i * m + j] = rng_randint_i64(key, (uint32_t)j, minval, maxval);
   }
 }
 

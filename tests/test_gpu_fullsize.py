@@ -321,16 +321,17 @@ def test_full_length_pmsm_tsit5_fp32_10000_steps():
     _assert_drift(dr, C3_BOUNDS)
 
 
-# Bounds on the chained full-horizon curves (units: full scale of each normalised observation, angles on the circle; `rel` = the same
-# difference over max(1, |oracle|): PMSM's random-voltage trajectories leave the normalisation box by a factor of up to 38).
+# Bounds on the chained full-horizon curves (units: full scale of each normalised observation, angles on the circle).
 # Measured in round 5 (256 environments, one MI355X; DESIGN.md §5 has the table):
-#   C3 PMSM Euler fp32, 10 000 chained steps: a (kernel vs fp32 oracle) max 5.0e-5 = 1.3e-6 relative, median environment 7.6e-6;
-#      c (fp32 oracle vs fp64 oracle, the floor of ANY fp32 implementation) max 4.3e-3, median 7.6e-4 -> the kernel's own share of the
-#      distance to the fp64 reference arithmetic is 1 %. PMSM Tsit5: a 3.2e-5, c 3.3e-3.
+#   C3 PMSM Euler fp32, 10 000 chained steps: a (kernel vs fp32 oracle) 2.4e-6 at row 100, 2.9e-5 at row 1 000, then a plateau —
+#      5.0e-5 at row 10 000, median environment 7.6e-6 (the current dynamics forget a perturbation within ~250 steps; what
+#      accumulates over that window are the <= 2 ulp differences between the device's and libm's sin / cos in the Park rotation);
+#      c (fp32 oracle vs fp64 oracle, the floor of ANY fp32 implementation) grows to 4.3e-3 (median 7.6e-4): the kernel's own
+#      share of the distance to the fp64 reference arithmetic is 1 %. PMSM Tsit5: a 3.2e-5, c 3.3e-3.
 #   C2 pendulum Euler fp32 (tau = 2e-2, random torque, no damping: chaotic): a <= 1.9e-6 over the first 100 rows, then a and c both
 #      grow to O(1) on the same curve (median environment at row 10 000: a 1.6e-2, c 2.2e-2) — no fp32 implementation can hold a fixed
 #      bound there, so the assertion is that the kernel stays BELOW the fp32 floor's curve.
-C3_BOUNDS = {"a_max": 1e-4, "a_rel_max": 1e-5, "a_over_c_last": 0.05}
+C3_BOUNDS = {"a_first_100": 1e-5, "a_max": 1e-4, "a_p50": 2e-5, "a_over_c_last": 0.05}
 C2_BOUNDS = {"a_first_100": 1e-5, "a_over_c_p50": 1.5, "a_over_c_p99": 1.5}
 
 
@@ -338,8 +339,8 @@ def _assert_drift(dr, bounds):
     last = -1
     if "a_max" in bounds:
         assert dr["a"]["max"][last] <= bounds["a_max"], dr["a"]
-    if "a_rel_max" in bounds:
-        assert dr["a_rel"]["max"][last] <= bounds["a_rel_max"], dr["a_rel"]
+    if "a_p50" in bounds:
+        assert dr["a"]["p50"][last] <= bounds["a_p50"], dr["a"]
     if "a_over_c_last" in bounds:
         assert dr["a"]["max"][last] <= bounds["a_over_c_last"] * dr["c"]["max"][last], (dr["a"]["max"], dr["c"]["max"])
     if "a_first_100" in bounds:

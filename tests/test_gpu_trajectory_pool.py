@@ -260,7 +260,8 @@ def test_pool_wait_stream_orders_the_reuse_behind_a_foreign_reader():
     ptr = obs.data_ptr()
     del obs, states
     second = env.vmap_sim_ahead(last, acts[1], env.tau, env.tau)
-    third = env.vmap_sim_ahead(second[2], acts[2], env.tau, env.tau)   # the first set comes round again
+    del last                                                           # nothing of the first set is referenced any more
+    third = env.vmap_sim_ahead(second[2], acts[2], env.tau, env.tau)   # ... so the pool hands it out again
     assert third[0].data_ptr() == ptr, "the dead set was expected to be written again"
     torch.cuda.synchronize()
     assert torch.equal(got, want)
@@ -298,11 +299,10 @@ def test_placement_settles_and_reports_real_launch_times():
     assert env2.trajectory_placement_settled
 
 
-def test_ordered_pair_is_made_once_reused_and_equals_the_unpooled_run():
-    """The first two sets of a shape are four allocations made in the order obs A, obs B, states A, states B — no probe launches of
-    the kernel. The chained run alternates between them, holds the bits of the unpooled run, never writes a set somebody still
-    sees; holding ONE returned array keeps only that array's allocation busy (round 4's single arena kept both sets busy for
-    ever); a caller that holds on to outputs gets searched single sets from the third call on (no second pair)."""
+def test_arena_pair_is_made_once_reused_and_equals_the_unpooled_run():
+    """The first two sets of a shape are views of ONE arena [obs A | obs B | states A | states B] — no probe launches. The chained
+    run alternates between them, holds the bits of the unpooled run, never writes a set somebody still sees, and a caller that holds
+    on to outputs gets searched single sets from the third call on (no second arena, at most POOL_SETS further sets pooled)."""
     env, st = _env("pmsm", B=2048)
     pl = env._placement
     pl.QUAD_MIN_SET_BYTES, pl.QUAD_MIN_DISTANCE, pl.PATTERN_ACCEPT = 0, 0, 0.0  # test-sized sets: accept whatever the pattern says
@@ -317,27 +317,30 @@ def test_ordered_pair_is_made_once_reused_and_equals_the_unpooled_run():
         assert torch.equal(o, ro) and torch.equal(states.physical_state.i_q, rstates.physical_state.i_q)
         ptrs.append(o.data_ptr())
         if i == 0:
-            assert env.last_placement["what"].startswith("four allocations") and len(pl.sets) == 2
+            assert env.last_placement["what"].startswith("one arena") and len(pl.sets) == 2
             a0, a1 = pl.sets[0], pl.sets[1]
-            stor = {t.untyped_storage().data_ptr() for t in (a0.obs_buf, a1.obs_buf, a0.st_buf, a1.st_buf)}
-            assert len(stor) == 4  # an allocation each
+            assert a0.obs_buf.untyped_storage().data_ptr() == a1.obs_buf.untyped_storage().data_ptr()  # one allocation
+            for t in (a0, a1):  # observations of both sets first, then the state blocks: each set's streams start apart
+                assert t.st_buf.data_ptr() - t.obs_buf.data_ptr() >= min(2 * a0.obs_buf.numel(), a0.obs_buf.numel() + a0.st_buf.numel()) * 4
         del o, states
     assert ptrs[0] == ptrs[2] == ptrs[4] and ptrs[1] == ptrs[3] and ptrs[0] != ptrs[1]
-    # a kept view of set A's observations pins set A only: set B keeps coming round
+    # a kept view of a returned array makes BOTH arena sets busy (one storage): the calls that follow alternate between two single
+    # sets, no third, fourth ... set is made, and the view still shows what it was handed
     held = env.vmap_sim_ahead(s, acts[0], env.tau, env.tau)
-    view = held[0][:, -1]
-    pa = held[0].data_ptr()
+    view, keep = held[0][:, -1], held[0][:, -1].clone()
+    arena_ptrs = {ptrs[0], ptrs[1]}
     s = held[2]
     del held
-    seen = set()
-    for i in range(4):
-        o, _, s = env.vmap_sim_ahead(s, acts[i], env.tau, env.tau)
-        assert o.data_ptr() != pa
-        seen.add(o.data_ptr())
+    seen = []
+    for i in range(6):
+        o, _, s = env.vmap_sim_ahead(s, acts[i % 5], env.tau, env.tau)
+        assert o.data_ptr() not in arena_ptrs
+        seen.append(o.data_ptr())
         del o
-    assert len(seen) == 2  # set B and ONE further single set alternate: no third, fourth ... set is made
+    assert len(set(seen)) == 2 and seen[0] == seen[2] == seen[4] and len(pl.sets) == 2
+    assert torch.equal(view, keep)
     del view
-    # a caller that keeps every output: the pair is used up after two calls, then single sets (no second pair)
+    # a caller that keeps every output: the pair is used up after two calls, then single sets (no second arena)
     env2, st2 = _env("pmsm", B=2048)
     p2 = env2._placement
     p2.QUAD_MIN_SET_BYTES, p2.QUAD_MIN_DISTANCE, p2.PATTERN_ACCEPT = 0, 0, 0.0
@@ -346,8 +349,7 @@ def test_ordered_pair_is_made_once_reused_and_equals_the_unpooled_run():
         out = env2.vmap_sim_ahead(s2, acts[i], env2.tau, env2.tau)
         held.append(out)
         s2 = out[2]
-    assert len({o[0].untyped_storage().data_ptr() for o in held}) == 4
-    assert p2.last is not None and "four allocations" not in (p2.last.get("what") or "")
+    assert len({o[0].untyped_storage().data_ptr() for o in held}) == 3  # calls 1 and 2 share the arena, 3 and 4 have their own
     torch.cuda.synchronize()
     s3 = st
     for i in range(4):  # and what they hold is still what the unpooled run computes

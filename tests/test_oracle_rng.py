@@ -160,6 +160,64 @@ def test_random_state_and_update_ref_structure(env_name, golden):
     assert np.array_equal(h2[~due], hold[~due] - 1) and np.array_equal(k2[~due], keys[~due])
     sp = oracle.split(leaf)
     assert np.array_equal(k2[due], sp[due, 0])
-    assert np.array_equal(h2[due], oracle.randint(sp[:, 1], 1, 10, 1000)[due, 0] - 1)
+    assert np.array_equal(h2[due], oracle.randint64(sp[:, 1], 1, 10, 1000)[due, 0] - 1)  # float64 arrays <=> x64: the int64 form
     for r, f in zip(new_refs, ctl):
         assert np.array_equal(r[due], st[f][due]) and np.all(r[~due] == 0.25)
+
+
+def _randint_bigint(key, m, minval, maxval, nbits):
+    """jax/_src/random.py _randint restated with Python integers (no fixed-width arithmetic at all: every wrap-around is an explicit
+    `% 2**nbits`), on top of the oracle's threefry / split — an arithmetic path independent of the three product / oracle twins."""
+    mask = (1 << nbits) - 1
+    k1, k2 = oracle.split(np.asarray(key))
+    out = []
+    for i in range(m):
+        def bits(k):
+            o0, o1 = oracle.threefry2x32(int(k[0]), int(k[1]), 0, i)
+            return (o0 ^ o1) if nbits == 32 else ((o0 << 32) | o1)
+        higher, lower = bits(k1), bits(k2)
+        span = (maxval - minval) & mask
+        if maxval <= minval:
+            span = 1
+        mult = (1 << (nbits // 2)) % span
+        mult = ((mult * mult) & mask) % span
+        off = ((((higher % span) * mult) & mask) + (lower % span) & mask) % span
+        out.append(minval + off)
+    return out
+
+
+def test_randint_in_the_x64_form_against_a_big_integer_restatement():
+    """VERDICT r04 missing 2: the reference's tests run jax_enable_x64, where gym_wrapper.py:183-188's randint draws int64 (two 64-bit
+    draws, uint64 arithmetic). Oracle (C), host twin (torch, int64 tensors standing for uint64) and the big-integer restatement
+    agree; the int32 form is checked the same way. PARITY UNPINNED for the x64 form: no published value is known."""
+    keys = oracle.split(oracle.prng_key(2024), 64)
+    for lo, hi in ((10, 1000), (0, 1), (5, 5), (7, 3), (-20, 40), (0, (1 << 31) - 1), (1, 1 << 20)):
+        want32 = [_randint_bigint(k, 3, lo, hi, 32) for k in keys]
+        want64 = [_randint_bigint(k, 3, lo, hi, 64) for k in keys]
+        assert oracle.randint(keys, 3, lo, hi).tolist() == want32, (lo, hi)
+        assert oracle.randint64(keys, 3, lo, hi).tolist() == want64, (lo, hi)
+        tk = torch.as_tensor(keys)
+        assert jr.randint(tk, 3, lo, hi).tolist() == want32, (lo, hi)
+        if hi - lo < (1 << 31):
+            assert jr.randint(tk, 3, lo, hi, x64=True).tolist() == want64, (lo, hi)
+    # the two forms are different streams (a float64 GymWrapper follows the x64 one): they must not coincide by construction
+    a, b = oracle.randint(keys, 1, 10, 1000)[:, 0], oracle.randint64(keys, 1, 10, 1000)[:, 0]
+    assert (a != b).mean() > 0.9 and a.min() >= 10 and a.max() < 1000 and b.min() >= 10 and b.max() < 1000
+    with pytest.raises(NotImplementedError):
+        jr.randint(torch.as_tensor(keys), 1, 0, 1 << 40, x64=True)
+
+
+def test_update_ref_draws_the_hold_time_in_the_dtype_default_int_form():
+    """oracle.update_ref (GymWrapper.update_ref, gym_wrapper.py:170-192): float32 environments draw int32 hold times, float64 ones the
+    x64 form."""
+    from helpers import spec_of
+
+    spec = spec_of("pendulum")
+    B = 32
+    keys = oracle.split(oracle.prng_key(5), B)
+    for dt, fn in ((np.float32, oracle.randint), (np.float64, oracle.randint64)):
+        props, keep = oracle.make_props("pendulum", spec["params"], spec["phys_norm"], spec["act_norm"], dt, B)
+        refs, k_out, h_out = oracle.update_ref("pendulum", [0], [np.zeros(B, dtype=dt)], keys, np.zeros(B, dtype=np.int64), props, dt, 10, 1000)
+        _, leaf = oracle.random_state("pendulum", keys, props, dt)
+        sub = oracle.split(leaf)[:, 1]
+        assert (h_out == fn(sub, 1, 10, 1000)[:, 0] - 1).all(), dt
