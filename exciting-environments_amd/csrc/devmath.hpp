@@ -28,8 +28,9 @@ __device__ __forceinline__ float xabs(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ double xabs(double a) { return __builtin_fabs(a); }
 __device__ __forceinline__ float xsqrt(float a) { return __builtin_sqrtf(a); }  // correctly rounded (hipcc default)
 __device__ __forceinline__ double xsqrt(double a) { return __builtin_sqrt(a); }
-__device__ __forceinline__ float xfmod_slow(float a, float b) { return fmodf(a, b); }
-__device__ __forceinline__ double xfmod_slow(double a, double b) { return fmod(a, b); }
+// (the library's bit-serial remainder loop: out of line, see sincos_lib below — taken only for |x| / 2 pi >= 2^22, NaN, inf)
+__device__ __attribute__((noinline)) float xfmod_slow(float a, float b) { return fmodf(a, b); }
+__device__ __attribute__((noinline)) double xfmod_slow(double a, double b) { return fmod(a, b); }
 
 // jnp.maximum / jnp.minimum against a bound: NaN in x propagates (jnp.clip semantics).
 template <typename T> __device__ __forceinline__ T max_nan(T x, T lo) { return (x < lo) ? lo : x; }
@@ -132,30 +133,37 @@ __device__ __forceinline__ void div_all(const InvDiv<T>* const (&d)[N], const T 
   }
 }
 
+// the same without the test: `bad` collects "some quotient needs the plain division" for the caller's one test per block
+template <int N, typename T>
+__device__ __forceinline__ void div_all_defer(const InvDiv<T>* const (&d)[N], const T (&num)[N], T (&out)[N], bool& bad) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) out[j] = d[j]->fastq(num[j], bad);
+}
+
 // Exact C fmod(|x|, Y) for the compile-time divisor Y = 2*pi, without the library's bit-serial loop:
 // the truncated quotient is estimated with a reciprocal multiply (off by at most one for |q| < 2^22),
 // the remainder |x| - q*Y is then a single exactly-representable fma, re-derived if the estimate was off.
 // Falls back to the library for huge quotients. Then the jnp.remainder sign fix (result takes the
 // divisor's sign): lax.rem + select(add) — reference semantics of `%` in e.g. pendulum_env.py:188.
+// Round 5: straight-line. The three-way fix-up of the estimate used to be nested per-lane branches (s_and_saveexec / s_xor /
+// s_cbranch_execz per level: ~10 scalar instructions per call next to 8 vector ones, in kernels whose waves are bound by how
+// many instructions of ANY kind they issue); now the adjusted quotient is selected and the remainder re-derived unconditionally
+// (fma(-q, Y, |x|) with the unadjusted q gives the first remainder's bits again), and the one remaining guard — a quotient too
+// large for the estimate, NaN, inf — is wave-uniform. Same values as before, bit for bit (test_device_pymod_*).
 template <typename T> __device__ __forceinline__ T pymod_two_pi(T x) {
   const T y = K<T>::two_pi;
-  T ax = xabs(x);
-  T q = xtrunc(ax * K<T>::inv_two_pi);
-  T r;
-  if (__builtin_expect(!(q < T(4194304.0)), 0)) {
-    r = xfmod_slow(ax, y);  // also takes NaN / inf
-  } else {
-    r = xfma(-q, y, ax);
-    if (r < T(0)) {
-      q -= T(1);
-      r = xfma(-q, y, ax);
-    } else if (r >= y) {
-      q += T(1);
-      r = xfma(-q, y, ax);
-    }
+  const T ax = xabs(x);
+  const T q = xtrunc(ax * K<T>::inv_two_pi);
+  const bool big = !(q < T(4194304.0));  // also NaN / inf
+  const T r0 = xfma(-q, y, ax);
+  const T qa = (r0 < T(0)) ? q - T(1) : ((r0 >= y) ? q + T(1) : q);
+  T r = xfma(-qa, y, ax);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(big) != 0, 0)) {
+    const T lib = xfmod_slow(ax, y);
+    r = big ? lib : r;
   }
-  r = (x < T(0)) ? -r : r;  // fmod carries the dividend's sign
-  if (r < T(0)) r = r + y;  // Python-style: shift negatives by the (positive) divisor
+  r = (x < T(0)) ? -r : r;       // fmod carries the dividend's sign
+  r = (r < T(0)) ? r + y : r;    // Python-style: shift negatives by the (positive) divisor
   return r;
 }
 
@@ -171,12 +179,37 @@ template <typename T> __device__ __forceinline__ T wrap_angle(T th) { return pym
 // device library's full-range routine (Payne-Hanek) takes over.
 __device__ __forceinline__ void sincos_t(double x, double& s, double& c) { ::sincos(x, &s, &c); }
 
+__device__ __forceinline__ void sincos_fast(float x, float& s, float& c);
+// The device library's full-range routines (Payne-Hanek reduction: ~300 instructions for the pair) as a REAL function: once per
+// code object instead of once per call site. Inlined, every sincos_t of a trajectory loop carried its own copy — the lean gym
+// loops of cart-pole / acrobot (20 call sites per half loop) were 80 KB, 130 KB after the guards became wave-uniform; with the
+// call they are 44 KB, register counts unchanged, no scratch (round 5, tools/loop_code_size.py). Never executed for |x| <= 65536.
+#ifndef EXCENV_SLOW_PATHS_NOINLINE
+#define EXCENV_SLOW_PATHS_NOINLINE 1
+#endif
+#if EXCENV_SLOW_PATHS_NOINLINE
+#define EXCENV_SLOW_FN __device__ __attribute__((noinline))
+#else
+#define EXCENV_SLOW_FN __device__ __forceinline__
+#endif
+EXCENV_SLOW_FN float2 sincos_lib(float x) { return make_float2(::sinf(x), ::cosf(x)); }
 __device__ __forceinline__ void sincos_t(float x, float& s, float& c) {
-  if (__builtin_expect(!(xabs(x) <= 65536.0f), 0)) {
-    s = ::sinf(x);
-    c = ::cosf(x);
-    return;
+  sincos_fast(x, s, c);
+  const bool big = !(xabs(x) <= 65536.0f);  // also NaN / inf
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(big) != 0, 0)) {  // wave-uniform guard (a per-lane one costs an exec-mask dance per call)
+    const float2 l = sincos_lib(x);
+    s = big ? l.x : s;
+    c = big ? l.y : c;
   }
+}
+// The fast path alone (valid for |x| <= 65536) + its guard OR-ed into `bad`: a caller that evaluates several independent rows as
+// ONE straight-line block (the flush of kernels_emr.hpp) tests `bad` once per block and redoes the block with the guarded forms —
+// the guards of sincos_t / InvDiv::div end basic blocks, and the chains of independent rows cannot interleave across them.
+__device__ __forceinline__ void sincos_defer(float x, float& s, float& c, bool& bad) {
+  bad = bad || !(xabs(x) <= 65536.0f);
+  sincos_fast(x, s, c);
+}
+__device__ __forceinline__ void sincos_fast(float x, float& s, float& c) {
   float n = __builtin_rintf(x * 0.63661977236758134308f);  // x * 2/pi
   float r = xfma(-n, 1.5703125f, x);                        // pi/2 split in three (Cephes DP1..3 doubled)
   r = xfma(-n, 4.837512969970703125e-4f, r);

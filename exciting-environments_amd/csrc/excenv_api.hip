@@ -185,7 +185,8 @@ int excenv_sim_ahead_fuses_actions(int env, int solver, int dtype, int64_t B, in
   int trc;
   const EnvVTable* t = table_for(env, props, &trc);
   if (!t) return 0;
-  return aem_applies(env, props->pmsm_lut != nullptr, props_batched(props, t->P, t->S, t->A) || n_control > 0 || with_gym != 0, t->A,
+  (void)n_control;  // control columns are filled behind the lean kernel (control_fill_kernel): no reason not to fuse
+  return aem_applies(env, props->pmsm_lut != nullptr, props_batched(props, t->P, t->S, t->A) || with_gym != 0, t->A,
                      dtype == EXCENV_F64 ? 8 : 4, B, K, solver, opts->envs_per_lane, action_layout, traj_layout, opts->flags, actions)
              ? 1 : 0;
 }
@@ -229,8 +230,10 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
   const int64_t need = excenv_sim_ahead_workspace_bytes(env, dtype, B, K, substeps, nc, action_layout, traj_layout,
                                                         state_traj != nullptr);
   // row-major actions + lane-major trajectories: the trajectory kernel reads the actions itself (no workspace, no extra pass)
+  bool refs_ok = true;  // control columns next to fused actions need every reference array (control_fill_kernel reads them)
+  for (int j = 0; j < nc; ++j) refs_ok &= control->reference[j] != nullptr;
   const bool fused_actions =
-      aem_applies(env, props->pmsm_lut != nullptr, props_batched(props, t->P, t->S, t->A) || nc > 0 || gym != nullptr, t->A,
+      aem_applies(env, props->pmsm_lut != nullptr, props_batched(props, t->P, t->S, t->A) || !refs_ok || gym != nullptr, t->A,
                   (size_t)wbytes, B, K, solver, opts->envs_per_lane, action_layout, traj_layout, opts->flags, actions) &&
       aligned16(obs_traj);
   const bool via_ws = !fused_em && !fused_actions && !gym && workspace && need > 0 && workspace_bytes >= need && B > 0 &&

@@ -63,6 +63,15 @@ template <class M, typename T, bool AHEAD> constexpr size_t emr_lds_bytes() { re
 #ifndef EXCENV_EMR_ROW_UNROLL
 #define EXCENV_EMR_ROW_UNROLL 1  // observation rows evaluated together at flush time (models with more than two ring leaves)
 #endif
+#ifndef EXCENV_EMR_DEFER
+#define EXCENV_EMR_DEFER 1       // the observation rows of a flush as branch-free blocks of EXCENV_EMR_DEFER_ROWS rows (see flush)
+#endif
+#ifndef EXCENV_EMR_DEFER_ROWS
+#define EXCENV_EMR_DEFER_ROWS 4
+#endif
+#ifndef EXCENV_EMR_UNROLL_LINES
+#define EXCENV_EMR_UNROLL_LINES 0  // 1: the lines of a window unrolled — static ring indices instead of s_set_gpr_idx reads, 4 x the row code
+#endif
 #ifndef EXCENV_EMR_NT
 #define EXCENV_EMR_NT 1  // whole-run stores of the flush are non-temporal (plain stores: 10 ... 11 ms instead of 7 for the headline launch)
 #endif
@@ -262,16 +271,16 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
     // observation lines: line l of the window holds rows [l * RPO, (l + 1) * RPO)
     const int po = lane % NPL;
     const unsigned lane_rows_o = (unsigned)((int64_t)P * (lane - po) * rowlen);
+#if EXCENV_EMR_UNROLL_LINES
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int l = 0; l < NLO; ++l) {
       if ((l + 1) * RPO - 1 < s_lo || l * RPO > s_hi) continue;  // wave-uniform
       // the rows' observation values go into the transposition buffer piece by piece as they are produced (a whole line of them in
       // registers would cost 32 more)
-      auto row = [&](int t) __attribute__((always_inline)) {
-        T fs[S], ob[O];
-#pragma unroll
-        for (int j = 0; j < S; ++j) fs[j] = ring_get(j, l * RPO + t);
-        M::observe(fs, c, ob);
+      auto put_row = [&](int t, const T (&ob)[O]) __attribute__((always_inline)) {
         if constexpr (O >= VW) {
 #pragma unroll
           for (int m = 0; m < O / VW; ++m) {
@@ -287,7 +296,54 @@ __global__ void __launch_bounds__(EM_LANES) __attribute__((amdgpu_waves_per_eu(2
           for (int q = 0; q < O; ++q) xp[(i * EM_LANES + (lane ^ i)) * VW + (t * O + q) % VW] = ob[q];
         }
       };
-      if constexpr (NR <= 2 || EXCENV_EMR_ROW_UNROLL >= RPO) {  // the rows of a line as straight-line code
+      auto row_state = [&](int t, T (&fs)[S]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) fs[j] = ring_get(j, l * RPO + t);
+      };
+      auto row = [&](int t) __attribute__((always_inline)) {
+        T fs[S], ob[O];
+        row_state(t, fs);
+        M::observe(fs, c, ob);
+        put_row(t, ob);
+      };
+      if constexpr (EXCENV_EMR_DEFER && observe_defer_ok<M, T>()) {
+        // Round 5: G rows as ONE straight-line block. A wave of this kernel carries one environment per lane, so a row's
+        // generate_observation is one dependent chain (sin / cos -> ..., six normalisations) and the guards inside sincos_t /
+        // InvDiv::div end basic blocks: unrolled rows could not interleave (round 4: two / four rows "together" measured flat).
+        // observe_defer has no branch; its guards are tested once per block, and a block that fails (|angle| > 65536, a quotient
+        // outside the moderate range, NaN / inf) is redone with the guarded M::observe — same bits either way.
+        // (rows per block: four, two where the ring already holds 96 registers — PMSM's six leaves on the step-semantics path —
+        // so that nothing spills)
+        constexpr int GW = (NR * W * (int)sizeof(T) / 4 >= 96) ? 2 : EXCENV_EMR_DEFER_ROWS;
+        constexpr int G = RPO < GW ? RPO : GW;
+#pragma unroll
+        for (int t0 = 0; t0 < RPO; t0 += G) {
+          T obv[G][O];
+          bool bad = false;
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            T fs[S];
+            row_state(t0 + g, fs);
+            observe_defer<M, T>(fs, c, obv[g], bad);
+          }
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+#pragma unroll 1
+            for (int g = 0; g < G; ++g) {
+              T fs[S], ob[O];
+              row_state(t0 + g, fs);
+              M::observe(fs, c, ob);
+#pragma unroll
+              for (int gg = 0; gg < G; ++gg)
+                if (gg == g) {
+#pragma unroll
+                  for (int q = 0; q < O; ++q) obv[gg][q] = ob[q];
+                }
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < G; ++g) put_row(t0 + g, obv[g]);
+        }
+      } else if constexpr (NR <= 2 || EXCENV_EMR_ROW_UNROLL >= RPO) {  // the rows of a line as straight-line code
 #pragma unroll
         for (int t = 0; t < RPO; ++t) row(t);
       } else if constexpr (EXCENV_EMR_ROW_UNROLL == 2 && RPO % 2 == 0) {  // two rows' chains interleaved by the scheduler

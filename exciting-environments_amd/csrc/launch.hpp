@@ -510,8 +510,13 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
   for (int j = 0; lean_gym && j < ka.n_control; ++j) lean_gym = sc.control->reference[j] != nullptr && aligned16(sc.control->reference[j]);
   // the four-leaf models in fp64 with an RK solver would need more than 256 registers in that form (one wave per SIMD): general
   if (sizeof(T) == 8 && M::S == 4 && sc.solver != EXCENV_EULER) lean_gym = false;
+  // row-major actions the lean kernel can read itself (AEM) are no reason for the general kernel either: the control columns are
+  // filled behind it all the same (round 5; before, a control_state alone sent a plain [B, K, A] call to the transposition pass)
+  const bool aem_candidate = !batched && !with_gym && vec_ok && aligned16(sc.obs_traj) &&
+                             aem_applies(M::ID, M::HAS_LUT, false, M::A, sizeof(T), sc.B, sc.K, sc.solver, sc.vec_pref, sc.action_layout,
+                                         sc.traj_layout, sc.flags, sc.actions);
   bool split_control = !batched && (!with_gym || lean_gym) && ka.n_control > 0 && sc.traj_layout != EXCENV_LAYOUT_ENV_MAJOR &&
-                       sc.action_layout != EXCENV_LAYOUT_ENV_MAJOR && sc.B > 0;
+                       (sc.action_layout != EXCENV_LAYOUT_ENV_MAJOR || aem_candidate) && sc.B > 0;
   if (split_control) {
     for (int j = 0; j < ka.n_control; ++j) split_control &= sc.control->reference[j] != nullptr;
   }

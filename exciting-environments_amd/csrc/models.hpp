@@ -140,6 +140,9 @@ template <typename T> struct CartPole {
   }
 };
 
+#ifndef EXCENV_ACROBOT_ANGLE_SUM
+#define EXCENV_ACROBOT_ANGLE_SUM 0  // fp32 only; see Acrobot::f
+#endif
 // ---- Acrobot: acrobot_env.py:171-197,247-248 ; P = (g,l_1,l_2,m_1,m_2,l_c1,l_c2,I_1,I_2) ----
 template <typename T> struct Acrobot {
   static constexpr int ID = EXCENV_ACROBOT, S = 4, A = 1, O = 4, P = 9, NY = 4, ND = 0;
@@ -165,8 +168,19 @@ template <typename T> struct Acrobot {
     const T d_22 = m_2 * (l_c2 * l_c2) + I_2;
     const T h_1 = -m_2 * l_1 * l_c2 * s2 * (omega_2 * omega_2) - T(2) * m_2 * l_1 * l_c2 * s2 * omega_1 * omega_2;
     const T h_2 = m_2 * l_1 * l_c2 * s2 * (omega_1 * omega_1);
-    const T cA = cos_t(theta_1 + K<T>::half_pi);
-    const T cB = cos_t(theta_1 + theta_2 + K<T>::half_pi);
+    T cA, cB;
+    if constexpr (EXCENV_ACROBOT_ANGLE_SUM != 0 && sizeof(T) == 4) {
+      // cos(x + pi/2) = -sin x and cos(x + y + pi/2) = -(sin x cos y + cos x sin y): ONE more sincos instead of two cos_t, whose
+      // argument sums each round first (the reference's expression, acrobot_env.py:182-183, kept literally in fp64 and in the
+      // oracle). Deviates from the literal form by the rounding of theta + pi/2 (~1e-7 in the argument): DESIGN.md §6.2b.
+      T s1, c1;
+      sincos_t(theta_1, s1, c1);
+      cA = -s1;
+      cB = -(s1 * c2 + c1 * s2);
+    } else {
+      cA = cos_t(theta_1 + K<T>::half_pi);
+      cB = cos_t(theta_1 + theta_2 + K<T>::half_pi);
+    }
     const T phi_1 = (m_1 * l_c1 + m_2 * l_1) * g * cA + m_2 * l_c2 * g * cB;
     const T phi_2 = m_2 * l_c2 * g * cB;
     const T d_omega_1 = T(1) / (d_12 - d_22 / d_12 * d_11) * (u[0] + d_22 / d_12 * (h_1 + phi_1) - h_2 - phi_2);
@@ -450,6 +464,46 @@ template <typename T> struct PmsmSat {
     L::constraint(a, eps, omega_el, c, uc);
   }
 };
+
+// generate_observation without a branch: the values of M::observe wherever `bad` stays false (same operations, same order — the
+// fast paths of sincos_t and InvDiv::div), garbage where it turns true; the caller redoes such a block with M::observe.
+// Available (returns true at compile time) for the fast-division trajectory kernels, PMSM in fp32 only (fp64 sin / cos are the
+// device library's).
+template <class M, typename T> constexpr bool observe_defer_ok() { return !(M::IS_PMSM && sizeof(T) == 8) && !M::HAS_LUT; }
+template <class M, typename T>
+__device__ __forceinline__ void observe_defer(const T (&st)[M::S], const Ctx<T, M>& c, T (&ob)[M::O], bool& bad) {
+  if constexpr (M::IS_PMSM) {  // Pmsm::observe
+    if constexpr (sizeof(T) == 4) {
+      T sn, cs;
+      sincos_defer(st[2], sn, cs, bad);
+      const InvDiv<T>* d[6] = {&c.nrm[3], &c.nrm[4], &c.nrm[6], &c.nrm[5], &c.nrm[0], &c.nrm[1]};
+      const T num[6] = {T(2) * (st[3] - c.smin[3]), T(2) * (st[4] - c.smin[4]), T(2) * (st[6] - c.smin[6]),
+                        T(2) * (st[5] - c.smin[5]), T(2) * (st[0] - c.smin[0]), T(2) * (st[1] - c.smin[1])};
+      T n[6];
+      div_all_defer<6, T>(d, num, n, bad);
+      ob[0] = n[0] - T(1);
+      ob[1] = n[1] - T(1);
+      ob[2] = n[2] - T(1);
+      ob[3] = n[3] - T(1);
+      ob[4] = cs;
+      ob[5] = sn;
+      ob[6] = n[4] - T(1);
+      ob[7] = n[5] - T(1);
+    }
+  } else {  // the other five: every state field normalised, in order (normalize_fields / normalize_field)
+    static_assert(M::IS_PMSM || M::O == M::S, "observation = the normalised state");
+    const InvDiv<T>* d[M::S];
+    T num[M::S], n[M::S];
+#pragma unroll
+    for (int j = 0; j < M::S; ++j) {
+      d[j] = &c.nrm[j];
+      num[j] = T(2) * (st[j] - c.smin[j]);
+    }
+    div_all_defer<M::S, T>(d, num, n, bad);
+#pragma unroll
+    for (int j = 0; j < M::S; ++j) ob[j] = n[j] - T(1);
+  }
+}
 
 // ---- reward / truncated / terminated (reference generate_reward / generate_truncated / generate_terminated) -----
 // What GymWrapper.gym_step evaluates after every vmap_step (gym_wrapper.py:117-126). `ref[j]` is the physical

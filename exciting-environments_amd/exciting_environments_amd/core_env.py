@@ -481,6 +481,8 @@ class CoreEnvironment(TrajectoryLaunchMixin, ABC):
         props, keep = self._props_for(env_properties, B)
         st_in = [self._t(getattr(state.physical_state, n), (B,)) for n in self.STATE_FIELDS]
         act = self._t(action, (B, self.action_dim))
+        if act.data_ptr() % 16:  # a row sliced out of a larger array (actions[b, k]): the kernels read action rows as 16-byte pieces
+            act = act.clone()
         control, refs = self._control(state, (B,))
         pad = (-B) % 4  # keep every leaf 16-byte aligned inside the single allocation
         buf = torch.empty(S * (B + pad) + B * O, dtype=self.dtype, device=self.device)
@@ -538,6 +540,8 @@ class CoreEnvironment(TrajectoryLaunchMixin, ABC):
             self._last_out = None
         if action.dtype is not self.dtype or action.device != dev or not action.is_contiguous():
             action = self._t(action, (B, self.action_dim))
+        if action.data_ptr() % 16:  # a contiguous slice that starts inside a 16-byte piece
+            action = action.clone()
         _native._require_device(action, "vmap_step")
         control_ref = None
         if self.control_state:

@@ -235,8 +235,9 @@ int excenv_sim_ahead_ws(int env, int solver, int dtype, int64_t B, int64_t K, in
 /* 1 when excenv_sim_ahead[_ws] with these arguments reads the row-major actions[B][K][A] (what the reference's
  * vmap_sim_ahead is handed, core_env.py:571-616) inside the lane-major trajectory kernel itself — 64-byte windows of every
  * environment's row through LDS, no transposition pass, no workspace — else 0 (then a workspace of
- * excenv_sim_ahead_workspace_bytes lets the library transpose them first). Applies to broadcast properties without control
- * columns / gym trajectories, the batch sizes that run V = 16 / sizeof(dtype) environments per lane with B % (64 V) == 0,
+ * excenv_sim_ahead_workspace_bytes lets the library transpose them first). Applies to broadcast properties without gym
+ * trajectories (control columns are fine when every control->reference[j] is given: they are filled by a second small launch
+ * behind the lean kernel; n_control is ignored by this query), the batch sizes that run V = 16 / sizeof(dtype) environments per lane with B % (64 V) == 0,
  * K * A * sizeof(dtype) a multiple of 16 and 16-byte aligned actions; the state / output pointers must be 16-byte aligned as
  * for every vectorised launch. */
 int excenv_sim_ahead_fuses_actions(int env, int solver, int dtype, int64_t B, int64_t K, const excenv_props_t* props,

@@ -133,3 +133,35 @@ def test_fused_row_major_actions_match_the_oracle_at_a_headline_sized_batch(env_
                 assert circ_close(g[..., None], s_ref[j][..., None], [0], rtol, atol * scale, period=2 * np.pi), name
             else:
                 assert np.allclose(g, s_ref[j], rtol=rtol, atol=atol * scale), (name, max_err(g, s_ref[j]))
+
+
+@pytest.mark.parametrize("env_name,control,dtype", [("pmsm", ["i_d", "i_q"], torch.float32), ("pendulum", ["theta"], torch.float32),
+                                                    ("cartpole", ["theta", "deflection"], torch.float64)])
+def test_fused_row_major_actions_with_control_columns(env_name, control, dtype):
+    """Round 5: a control_state alone no longer sends a plain [B, K, A] call to the transposition pass — the lean kernel reads the
+    row-major actions itself and control_fill_kernel fills the reference columns behind it. Same bits as the same call with
+    lane-major actions, and the columns hold the normalised references."""
+    B, K = 4096, 40
+    env, props, keep, spec = make_env(env_name, B, dtype, control_state=list(control))
+    env.launch_opts = _native.launch_opts(envs_per_lane=_vmax(dtype))
+    st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=61)
+    rng = np.random.default_rng(62)
+    refs = {}
+    for n in control:
+        lo, hi = spec["phys_norm"][n]
+        refs[n] = rng.uniform(lo, hi, B).astype(NP_DTYPE[dtype])
+    plain = torch.as_tensor(rng.uniform(-1, 1, (B, K, env.action_dim)).astype(NP_DTYPE[dtype]), device=env.device)
+    lane = env.new_actions_buffer(K)
+    lane.copy_(plain)
+    assert _fuses(env, plain, K, env.launch_opts)
+    want = env.vmap_sim_ahead(to_state(env, st, reference=refs), lane, env.tau, env.tau)
+    got = env.vmap_sim_ahead(to_state(env, st, reference=refs), plain, env.tau, env.tau)
+    torch.cuda.synchronize()
+    assert _native.last_launch() == "sim_ahead_kernel (row-major actions fused)"
+    _same(env, got, want)
+    O = got[0].shape[-1]
+    for j, n in enumerate(control):
+        lo, hi = spec["phys_norm"][n]
+        col = got[0][:, :, O - len(control) + j]
+        want_col = torch.as_tensor(2 * (refs[n] - lo) / (hi - lo) - 1, device=env.device)[:, None].expand_as(col)
+        assert torch.allclose(col, want_col, rtol=1e-6, atol=1e-6)

@@ -81,7 +81,8 @@ def test_abi_argument_validation_without_gpu():
     assert lib.excenv_allgather(vp(16), 0, None, None, i64(0), None) == 0  # nothing to gather
     assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(100), ctypes.byref(p), 0, 0, 0, 1, vp(16), None) == 1
     assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(101), ctypes.byref(p), 0, 0, 0, 1, vp(16), None) == 0  # 404-byte rows
-    assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(100), ctypes.byref(p), 1, 0, 0, 1, vp(16), None) == 0  # control columns
+    assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(100), ctypes.byref(p), 1, 0, 0, 1, vp(16), None) == 1  # control columns: filled behind the lean kernel
+    assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(100), ctypes.byref(p), 0, 1, 0, 1, vp(16), None) == 0  # gym trajectories
     assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 12), i64(100), ctypes.byref(p), 0, 0, 0, 1, vp(16), None) == 0  # small batch
     assert lib.excenv_sim_ahead_fuses_actions(0, 0, 0, i64(1 << 20), i64(100), ctypes.byref(p), 0, 0, 0, 0, vp(16), None) == 0  # row-major outputs
     off = _native.launch_opts(flags=_native.OPT_NO_FUSED_ACTIONS)
