@@ -438,9 +438,14 @@ template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return 
 // (tools/ab_same_buffers.py, profiles/r04_pattern_sweep.md). With more arithmetic per row (RK4 / Tsit5, cart-pole, acrobot, PMSM)
 // lockstep takes away the overlap of one wave's arithmetic with another's stores and the same change LOSES 2 ... 9 %: NT == BLOCK
 // there, no barrier. sim_threads<M, T>() (launch.hpp) is the rule.
+#ifndef EXCENV_SIM_MIN_WAVES  // build experiments: "amdgpu-waves-per-eu" lower bound of the trajectory kernel (register cap 512 / n)
+#define EXCENV_SIM_KERNEL_ATTR
+#else
+#define EXCENV_SIM_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(EXCENV_SIM_MIN_WAVES)))
+#endif
 template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false, bool LGYM = false,
           int NT = BLOCK>
-__global__ void __launch_bounds__(NT) sim_ahead_kernel(const SimArgs<T, M> ka) {
+__global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
   extern __shared__ __align__(16) unsigned char excenv_smem[];
   static_assert(NT == BLOCK || (!GENERAL && !AEM && !M::HAS_LUT), "wide workgroups: lean instantiations only (plain or with gym outputs)");

@@ -141,7 +141,7 @@ template <typename T> struct CartPole {
 };
 
 #ifndef EXCENV_ACROBOT_ANGLE_SUM
-#define EXCENV_ACROBOT_ANGLE_SUM 0  // fp32 only; see Acrobot::f
+#define EXCENV_ACROBOT_ANGLE_SUM 1  // fp32 only; see Acrobot::f (0: the literal cos(theta + pi/2) forms)
 #endif
 // ---- Acrobot: acrobot_env.py:171-197,247-248 ; P = (g,l_1,l_2,m_1,m_2,l_c1,l_c2,I_1,I_2) ----
 template <typename T> struct Acrobot {
