@@ -438,11 +438,17 @@ template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return 
 // (tools/ab_same_buffers.py, profiles/r04_pattern_sweep.md). With more arithmetic per row (RK4 / Tsit5, cart-pole, acrobot, PMSM)
 // lockstep takes away the overlap of one wave's arithmetic with another's stores and the same change LOSES 2 ... 9 %: NT == BLOCK
 // there, no barrier. sim_threads<M, T>() (launch.hpp) is the rule.
-#ifndef EXCENV_SIM_MIN_WAVES  // build experiments: "amdgpu-waves-per-eu" lower bound of the trajectory kernel (register cap 512 / n)
-#define EXCENV_SIM_KERNEL_ATTR
-#else
-#define EXCENV_SIM_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(EXCENV_SIM_MIN_WAVES)))
-#endif
+// Register caps (the "amdgpu-waves-per-eu" lower bound: 512 / n registers per lane). The compiler does not weigh a wave per SIMD
+// against a few registers: when the math primitives were restructured in round 5 these instantiations went from 205 ... 254 to
+// 259 ... 294 registers — one wave per SIMD instead of two (acrobot's gym trajectories: 4.9 -> 6.0 ms). Everything else keeps the
+// compiler's choice (the fp64 RK kernels of the four-leaf models and the look-up model need more than 256).
+template <class M, typename T, bool GENERAL, bool AEM, bool LGYM, int STATES> constexpr int sim_min_waves() {
+  if (LGYM && M::ID == EXCENV_ACROBOT && sizeof(T) == 4) return 2;
+  if (GENERAL && M::ID == EXCENV_PENDULUM && sizeof(T) == 8) return 2;
+  if (AEM && M::IS_PMSM && !M::HAS_LUT && sizeof(T) == 8 && STATES == 0) return 2;
+  return 1;
+}
+#define EXCENV_SIM_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(sim_min_waves<M, T, GENERAL, AEM, LGYM, STATES>())))
 template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false, bool LGYM = false,
           int NT = BLOCK>
 __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(const SimArgs<T, M> ka) {

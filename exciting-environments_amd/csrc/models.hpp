@@ -140,8 +140,16 @@ template <typename T> struct CartPole {
   }
 };
 
+// EXCENV_ACROBOT_ANGLE_SUM = 1 (build option, fp32 only, OFF by default): cos(theta_1 + pi/2) and cos(theta_1 + theta_2 + pi/2)
+// through -sin(theta_1) and -(sin theta_1 cos theta_2 + cos theta_1 sin theta_2) — one more sincos instead of two cos_t. Measured in
+// round 5 (same-session A/B, B = 2^22): acrobot Tsit5 8.97 -> 8.50 ms (0.211 -> 0.2225 of the HBM roof, +5.4 %), acrobot Euler flat.
+// Against the literal forms: identical for the first 10 rows of the reference's fixture, 1.2e-7 (full scale) at row 64, 3.6e-4 at
+// row 10 000 (both forms sit 1.5e-3 ... 1.9e-3 from the fp64 fixture there: the double pendulum's own amplification). It stays off
+// because the reference's expression rounds theta + pi/2 FIRST: at unwrapped angles of 1e4 ... 3e5 (sim_ahead integrates the raw
+// angle) that rounding is up to 0.015 rad, the identity does not reproduce it, and the oracle comparison at such angles
+// (test_unwrapped_angles_far_outside_the_principal_range) leaves its tolerance (2.1e-4 against 2e-4). Parity before 5 %.
 #ifndef EXCENV_ACROBOT_ANGLE_SUM
-#define EXCENV_ACROBOT_ANGLE_SUM 1  // fp32 only; see Acrobot::f (0: the literal cos(theta + pi/2) forms)
+#define EXCENV_ACROBOT_ANGLE_SUM 0
 #endif
 // ---- Acrobot: acrobot_env.py:171-197,247-248 ; P = (g,l_1,l_2,m_1,m_2,l_c1,l_c2,I_1,I_2) ----
 template <typename T> struct Acrobot {
