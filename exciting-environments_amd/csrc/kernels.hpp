@@ -818,7 +818,6 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
   constexpr int VW = 16 / (int)sizeof(T);  // elements per 16-byte piece
   constexpr int SP = AEM ? VW / A : 1;     // action rows per piece
   constexpr int NP = aem_np<M>();          // pieces per window
-  constexpr int RW = NP * SP;              // rows per window
   constexpr int EPI = 64 / NP;             // environments (reader lanes) per load instruction
   static_assert(64 % NP == 0, "a load instruction covers whole windows");
   const unsigned wave = threadIdx.x / 64u, lane64 = threadIdx.x % 64u;
@@ -831,63 +830,93 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
   const uint64_t ld_lane_off = AEM ? ((uint64_t)(wave * 64u + lane64 / NP) * V) * (uint64_t)ka.a_sb : 0;  // elements, before (i, v)
   const int64_t n_pieces = AEM ? (ka.K * A) / VW : 0;  // pieces per environment row (host: K * A % VW == 0)
   constexpr int NSTORE = O + ((STATES != 0) ? S : 0);   // trajectory stores per saved row: issued between a fill and its first read
-  int64_t w_hi = -1;                                    // highest window requested so far (wave-uniform)
-  auto dma_window = [&](int64_t w) __attribute__((always_inline)) {
+  // Sector-aligned windows (round 5). A window is NP pieces = 64 bytes and one fabric request — if it does not straddle two
+  // 64-byte sectors of memory. Rows of K * A * sizeof(T) bytes start on 16-byte boundaries only (PMSM, K = 100: 800 bytes, every
+  // second environment starts in the middle of a sector), so windows counted from the row's first byte straddled for half of the
+  // environments: 6.8e7 fabric reads where 5.2e7 would do, FETCH_SIZE 1.29 x the action bytes (round 4). Now the windows of an
+  // environment are the SECTORS its row touches: with ph = (first piece of the row) mod NP, row piece j sits at position
+  // (j + ph) % NP of window (j + ph) / NP, the first window holds NP - ph pieces (the lanes in front of it re-fetch the row's first
+  // piece, never read), every further one is one aligned sector. ph depends on the environment only through its slot v of the lane
+  // (the lanes' environments are V apart and V * pieces-per-row is a multiple of NP — else ph = 0 for everybody: the round-4
+  // scheme), so each slot keeps its own wave-uniform window count and refills when ITS window ends.
+  const bool aem_aligned = AEM && ((n_pieces * V) % NP) == 0;
+  unsigned aem_ph[V];
+  int64_t w_hi[V];  // highest window requested so far, per slot (wave-uniform)
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    aem_ph[v] = aem_aligned ? (unsigned)((((uintptr_t)a_blk >> 4) + (uint64_t)v * (uint64_t)n_pieces) % NP) : 0u;
+    w_hi[v] = -1;
+  }
+  auto dma_window = [&](int v, int64_t w) __attribute__((always_inline)) {  // v: compile-time constant at every call
     if constexpr (AEM) {
-      int64_t pc = w * NP + ld_piece;
-      pc = pc < n_pieces ? pc : n_pieces - 1;  // a short last window: the spare lanes fetch the last piece again (never read)
+      int64_t pc = w * NP + ld_piece - (int64_t)aem_ph[v];
+      pc = pc < 0 ? 0 : (pc < n_pieces ? pc : n_pieces - 1);  // in front of the row / behind it: a piece of the row again (never read)
       const T* lane_src = a_blk + ld_lane_off + pc * VW;
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-          // Inline assembly, not __builtin_amdgcn_global_load_lds: the compiler treats an LDS-direct load as a FLAT access and puts
-          // `s_waitcnt vmcnt(0)` in front of every later LDS read — that would drain the trajectory stores once per step. Hidden
-          // from it, the only wait is the counted one in load_action below. M0 = the LDS byte address of the block: declared as
-          // clobbered, and the s_nop is the wait state gfx9-family parts need between an SALU write of M0 and an LDS-direct load
-          // (the compiler's hazard recognizer emits the same s_nop behind the builtin; it does not look inside an asm string).
-          // tests/test_host_api.py checks both in the disassembly of the built library.
-          const T* src = lane_src + (uint64_t)(i * EPI * V + v) * (uint64_t)ka.a_sb;
-          // (M0 is a reserved register: clang warns that it "may not be preserved"; listing it is what makes the compiler's own M0
-          // initialisations — s_set_gpr_idx, its LDS-direct loads — see this statement as a redefinition)
+      for (int i = 0; i < NP; ++i) {
+        // Inline assembly, not __builtin_amdgcn_global_load_lds: the compiler treats an LDS-direct load as a FLAT access and puts
+        // `s_waitcnt vmcnt(0)` in front of every later LDS read — that would drain the trajectory stores once per step. Hidden
+        // from it, the only wait is the counted one in load_action below. M0 = the LDS byte address of the block: declared as
+        // clobbered, and the s_nop is the wait state gfx9-family parts need between an SALU write of M0 and an LDS-direct load
+        // (the compiler's hazard recognizer emits the same s_nop behind the builtin; it does not look inside an asm string).
+        // tests/test_isa_guards.py checks both in the disassembly of the built library.
+        const T* src = lane_src + (uint64_t)(i * EPI * V + v) * (uint64_t)ka.a_sb;
+        // (M0 is a reserved register: clang warns that it "may not be preserved"; listing it is what makes the compiler's own M0
+        // initialisations — s_set_gpr_idx, its LDS-direct loads — see this statement as a redefinition)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 #if EXCENV_FAULT & 4
-          asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(wave_lds + (unsigned)(v * NP + i) * AEM_BLOCK_BYTES) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(wave_lds + (unsigned)(v * NP + i) * AEM_BLOCK_BYTES) : "memory", "m0");
 #else
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(wave_lds + (unsigned)(v * NP + i) * AEM_BLOCK_BYTES)
-                       : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(wave_lds + (unsigned)(v * NP + i) * AEM_BLOCK_BYTES)
+                     : "memory", "m0");
 #endif
 #pragma clang diagnostic pop
-        }
       }
     }
   };
   auto load_action = [&](int64_t krow, T (&dst)[A][V]) __attribute__((always_inline)) {
     if constexpr (AEM) {
-      const int64_t w = krow / RW;
-      const unsigned r = (unsigned)(krow % RW), off = (r / SP) * 16u + (r % SP) * (unsigned)(A * sizeof(T));
-      // first row of a window that was requested one row earlier: everything but the trajectory stores issued since must be back
-      // (vmcnt retires in issue order: with exactly NSTORE vector-memory instructions behind the fill, vmcnt(NSTORE) waits for the
-      // fill and for nothing younger; FEWER than NSTORE behind it and the wait would prove nothing — tools/isa_guards.py counts them
-      // on every path of the built code). expcnt(6) never blocks here (no exports) and marks the hand-written waits for that tool.
-      // Wave-uniform.
-      if (r == 0) asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"((NSTORE + (EXCENV_FAULT & 1)) < 63 ? (NSTORE + (EXCENV_FAULT & 1)) : 63) : "memory");
+      const int64_t j = krow / SP;                  // the row's piece of its environment's row
+      const unsigned rs = (unsigned)(krow % SP);    // the row inside that piece
+      int64_t w[V];
+      unsigned pos[V];
+      bool opens = false;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int64_t q = j + (int64_t)aem_ph[v];
+        w[v] = q / NP;
+        pos[v] = (unsigned)(q % NP);
+        opens = opens || (pos[v] == 0 && rs == 0);
+      }
+      // first row of a window (of any slot) that was requested one row earlier: everything but the trajectory stores issued since
+      // must be back (vmcnt retires in issue order: with exactly NSTORE vector-memory instructions behind the fill, vmcnt(NSTORE)
+      // waits for the fill and for nothing younger — fills of other slots issued behind it only make the wait stricter; FEWER than
+      // NSTORE behind it and the wait would prove nothing — tools/isa_guards.py counts them on every path of the built code).
+      // expcnt(6) never blocks here (no exports) and marks the hand-written waits for that tool. Wave-uniform.
+      if (opens) asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"((NSTORE + (EXCENV_FAULT & 1)) < 63 ? (NSTORE + (EXCENV_FAULT & 1)) : 63) : "memory");
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         T rr[A];
+        const unsigned off = pos[v] * 16u + rs * (unsigned)(A * sizeof(T));
         load_row<T, A>(reinterpret_cast<const T*>(excenv_smem + wave_off + (unsigned)(v * NP) * AEM_BLOCK_BYTES + rd_lane + off), rr);
 #pragma unroll
         for (int q = 0; q < A; ++q) dst[q][v] = rr[q];
       }
-      // last row of the window, requested for the last time (with sub-steps a row is requested once as the row after the current
+      // last row of a slot's window, requested for the last time (with sub-steps a row is requested once as the row after the current
       // one and then once per further sub-step of its own action step; subn is the sub-step the requested row will serve): the
-      // window's LDS is dead once these reads have returned -> request the next window into it. w_hi: once per window, whatever
-      // the clamped tail of the trajectory repeats.
-      if (r == RW - 1 && subn == ka.substeps - 1 && w + 1 > w_hi && (w + 1) * NP < n_pieces) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dma_window(w + 1);
-        w_hi = w + 1;
+      // window's LDS is dead once these reads have returned -> request the slot's next window into it. w_hi: once per window,
+      // whatever the clamped tail of the trajectory repeats.
+      bool drained = false;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        if (pos[v] == NP - 1 && rs == SP - 1 && subn == ka.substeps - 1 && w[v] + 1 > w_hi[v] &&
+            (w[v] + 1) * NP - (int64_t)aem_ph[v] < n_pieces) {
+          if (!drained) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          drained = true;
+          dma_window(v, w[v] + 1);
+          w_hi[v] = w[v] + 1;
+        }
       }
     } else {
 #pragma unroll
@@ -917,8 +946,11 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
   };
   const int64_t klast = ka.K - 1;
   if constexpr (AEM) {  // the first window of every environment
-    dma_window(0);
-    w_hi = 0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      dma_window(v, 0);
+      w_hi[v] = 0;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once per trajectory (the initial state has arrived as well)
   }
   load_action(0, a0);
