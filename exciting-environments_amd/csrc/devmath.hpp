@@ -20,21 +20,21 @@ template <> struct K<double> {
   static constexpr double inv_two_pi = 0.15915494309189533577;
 };
 
-__device__ __forceinline__ float xfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double xfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ __forceinline__ float xtrunc(float a) { return __builtin_truncf(a); }
-__device__ __forceinline__ double xtrunc(double a) { return __builtin_trunc(a); }
-__device__ __forceinline__ float xabs(float a) { return __builtin_fabsf(a); }
-__device__ __forceinline__ double xabs(double a) { return __builtin_fabs(a); }
-__device__ __forceinline__ float xsqrt(float a) { return __builtin_sqrtf(a); }  // correctly rounded (hipcc default)
-__device__ __forceinline__ double xsqrt(double a) { return __builtin_sqrt(a); }
+__device__ __forceinline__ __attribute__((nodebug)) float xfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ __attribute__((nodebug)) double xfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ __attribute__((nodebug)) float xtrunc(float a) { return __builtin_truncf(a); }
+__device__ __forceinline__ __attribute__((nodebug)) double xtrunc(double a) { return __builtin_trunc(a); }
+__device__ __forceinline__ __attribute__((nodebug)) float xabs(float a) { return __builtin_fabsf(a); }
+__device__ __forceinline__ __attribute__((nodebug)) double xabs(double a) { return __builtin_fabs(a); }
+__device__ __forceinline__ __attribute__((nodebug)) float xsqrt(float a) { return __builtin_sqrtf(a); }  // correctly rounded (hipcc default)
+__device__ __forceinline__ __attribute__((nodebug)) double xsqrt(double a) { return __builtin_sqrt(a); }
 // (the library's bit-serial remainder loop: out of line, see sincos_lib below — taken only for |x| / 2 pi >= 2^22, NaN, inf)
 __device__ __attribute__((noinline)) float xfmod_slow(float a, float b) { return fmodf(a, b); }
 __device__ __attribute__((noinline)) double xfmod_slow(double a, double b) { return fmod(a, b); }
 
 // jnp.maximum / jnp.minimum against a bound: NaN in x propagates (jnp.clip semantics).
-template <typename T> __device__ __forceinline__ T max_nan(T x, T lo) { return (x < lo) ? lo : x; }
-template <typename T> __device__ __forceinline__ T min_nan(T x, T hi) { return (x > hi) ? hi : x; }
+template <typename T> __device__ __forceinline__ __attribute__((nodebug)) T max_nan(T x, T lo) { return (x < lo) ? lo : x; }
+template <typename T> __device__ __forceinline__ __attribute__((nodebug)) T min_nan(T x, T hi) { return (x > hi) ? hi : x; }
 // jnp.sign
 template <typename T> __device__ __forceinline__ T sign_of(T x) { return (x > T(0)) ? T(1) : ((x < T(0)) ? T(-1) : x); }
 
@@ -52,13 +52,24 @@ template <typename T> __device__ __forceinline__ T denormalize(T x, T lo, T hi) 
 // moderate quotient the result has the bits of the compiler's sequence; everything else (zero, inf, NaN, denormal, huge or
 // tiny operands, or a denominator outside the moderate range: y is NaN then) fails the range test on the quotient and takes
 // the plain `a / b`. Checked bit for bit on the GPU over random and edge-case operands (test_invariant_division_*).
+// The range test, round 5. It used to be two float compares per quotient (v_cmp into SGPR pairs, s_or, and an `s_nop` per
+// compare -> select hazard): for PMSM Tsit5 257 scalar instructions + 149 s_nops per wave-step, more than the divisions' own
+// arithmetic (tools/isa_tally.py). Now every quotient contributes its EXPONENT's distance from the low end of the window to an
+// unsigned running maximum (v_and, v_sub, v_max_u32: no scalar register involved; an exponent below the window wraps to a huge
+// value, NaN / inf carry the largest exponent) and a group of divisions is tested with ONE compare. The window in exponents,
+// [2^-60, 2^60) for fp32 and [2^-400, 2^400) for fp64, lies inside the old value window, so wherever the fast path is taken it is
+// taken under the same guarantee (the quotient has the bits of the compiler's division); zero still goes to the plain division.
 template <typename T> struct InvDivLimits;
 template <> struct InvDivLimits<float> {
-  static constexpr float b_lo = 0x1p-40f, b_hi = 0x1p40f, q_lo = 0x1p-60f, q_hi = 0x1p60f;
+  static constexpr float b_lo = 0x1p-40f, b_hi = 0x1p40f;
+  static constexpr uint32_t e_mask = 0x7F800000u, e_lo = (127u - 60u) << 23, e_span = (120u << 23) - 1u;  // exponents -60 .. +59
 };
 template <> struct InvDivLimits<double> {
-  static constexpr double b_lo = 0x1p-300, b_hi = 0x1p300, q_lo = 0x1p-400, q_hi = 0x1p400;
+  static constexpr double b_lo = 0x1p-300, b_hi = 0x1p300;
+  static constexpr uint32_t e_mask = 0x7FF00000u, e_lo = (1023u - 400u) << 20, e_span = (800u << 20) - 1u;  // exponents -400 .. +399, high word
 };
+__device__ __forceinline__ __attribute__((nodebug)) uint32_t exponent_word(float q) { return __float_as_uint(q); }
+__device__ __forceinline__ __attribute__((nodebug)) uint32_t exponent_word(double q) { return (uint32_t)__double2hiint(q); }
 
 template <typename T> struct InvDiv {
   T b, y;  // denominator; refined reciprocal (NaN when b is outside the moderate range -> every division takes `a / b`)
@@ -81,9 +92,9 @@ template <typename T> struct InvDiv {
     const T ab = xabs(b);
     y = (ab >= InvDivLimits<T>::b_lo && ab <= InvDivLimits<T>::b_hi) ? r : __builtin_nan("");
   }
-  // The fast quotient alone + its "needs the plain division" flag OR-ed into `slow`: lets a caller issue several
-  // independent divisions as straight-line code and test once (div_all below).
-  __device__ __forceinline__ T fastq(T a, bool& slow) const {
+  // The fast quotient alone; its exponent's distance from the window goes into the group's running maximum `acc` (start at 0,
+  // test with out_of_window()): lets a caller issue several independent divisions as straight-line code and test once.
+  __device__ __forceinline__ T fastq(T a, uint32_t& acc) const {
     T q = a * y;
     if constexpr (sizeof(T) == 4) {
       const T r0 = xfma(-b, q, a);
@@ -91,23 +102,18 @@ template <typename T> struct InvDiv {
     }
     const T r1 = xfma(-b, q, a);
     q = xfma(r1, y, q);
-    const T aq = xabs(q);
-    slow = slow || !(aq >= InvDivLimits<T>::q_lo && aq <= InvDivLimits<T>::q_hi);
+    const uint32_t d = (exponent_word(q) & InvDivLimits<T>::e_mask) - InvDivLimits<T>::e_lo;
+    acc = d > acc ? d : acc;
     return q;
   }
+  static __device__ __forceinline__ bool out_of_window(uint32_t acc) { return acc > InvDivLimits<T>::e_span; }
   // `fast` is a per-kernel compile-time constant carried in the Ctx (false on the one-step-per-launch path, where the
   // reciprocal would be set up and used once: plain division is cheaper there)
   __device__ __forceinline__ T div(T a, bool fast) const {
     if (!fast) return a / b;
-    T q = a * y;
-    if constexpr (sizeof(T) == 4) {
-      const T r0 = xfma(-b, q, a);
-      q = xfma(r0, y, q);
-    }
-    const T r1 = xfma(-b, q, a);
-    q = xfma(r1, y, q);
-    const T aq = xabs(q);
-    const bool slow = !(aq >= InvDivLimits<T>::q_lo && aq <= InvDivLimits<T>::q_hi);
+    uint32_t acc = 0;
+    T q = fastq(a, acc);
+    const bool slow = out_of_window(acc);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {  // wave-uniform: skipped entirely in the common case
       const T exact = a / b;
       q = slow ? exact : q;
@@ -124,10 +130,10 @@ __device__ __forceinline__ void div_all(const InvDiv<T>* const (&d)[N], const T 
     for (int j = 0; j < N; ++j) out[j] = num[j] / d[j]->b;
     return;
   }
-  bool slow = false;
+  uint32_t acc = 0;
 #pragma unroll
-  for (int j = 0; j < N; ++j) out[j] = d[j]->fastq(num[j], slow);
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {
+  for (int j = 0; j < N; ++j) out[j] = d[j]->fastq(num[j], acc);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(InvDiv<T>::out_of_window(acc)) != 0, 0)) {
 #pragma unroll
     for (int j = 0; j < N; ++j) out[j] = num[j] / d[j]->b;  // every lane: same bits as the fast path where that was valid
   }
@@ -136,8 +142,10 @@ __device__ __forceinline__ void div_all(const InvDiv<T>* const (&d)[N], const T 
 // the same without the test: `bad` collects "some quotient needs the plain division" for the caller's one test per block
 template <int N, typename T>
 __device__ __forceinline__ void div_all_defer(const InvDiv<T>* const (&d)[N], const T (&num)[N], T (&out)[N], bool& bad) {
+  uint32_t acc = 0;
 #pragma unroll
-  for (int j = 0; j < N; ++j) out[j] = d[j]->fastq(num[j], bad);
+  for (int j = 0; j < N; ++j) out[j] = d[j]->fastq(num[j], acc);
+  bad = bad || InvDiv<T>::out_of_window(acc);
 }
 
 // Exact C fmod(|x|, Y) for the compile-time divisor Y = 2*pi, without the library's bit-serial loop:

@@ -318,7 +318,8 @@ class TrajectoryPlacement:
     @property
     def settled(self) -> bool:
         """True once no later call can run a placement search: every pooled shape has its POOL_SETS sets, and each set is either
-        accepted by the absolute criterion (final at once) or past its decision window in real launches."""
+        accepted by the absolute criterion (final at once) or past its decision window in real launches (DECIDE_USES steady timings;
+        or the shape's replacements are used up)."""
         if not self.sets or not self.active or not self.env.trajectory_pool:
             return True
         for ts in self.sets:
@@ -334,9 +335,10 @@ class TrajectoryPlacement:
             for t in sets:
                 if t.judged_by_pattern:
                     continue
-                if t.steady_ms is None:
-                    return False
-                if self.replacement_due(t, [s for s in sets if s is not t]):
+                # judged by real launches: a set can be replaced while it has at most DECIDE_USES steady timings — until every such
+                # set is past that window a later call may still run a search (the running minimum of a sibling can still move the
+                # comparison: round 5, a search landed in a timed region 12 calls after `settled` had said True)
+                if t.steady_ms is None or t.uses <= self.DECIDE_USES:
                     return False
         return True
 

@@ -545,6 +545,11 @@ def test_placement_never_judges_a_set_on_its_first_launch():
     assert not pl.replacement_due(a, [b]) and not pl.replacement_due(b, [a])
     b.record_ms(4.8874)
     assert a.steady_ms == 4.8837 and b.steady_ms == 4.8874 and not pl.replacement_due(a, [b]) and not pl.replacement_due(b, [a])
+    assert not pl.settled  # still inside the decision window: a later launch could move the comparison
+    for _ in range(3):
+        a.record_ms(4.89)
+        b.record_ms(4.88)
+        assert not pl.replacement_due(a, [b]) and not pl.replacement_due(b, [a])
     assert pl.settled and pl.replaced == {}
     # sets accepted by the absolute criterion are final from the start: settled before any launch has been timed
     pl, (a, b) = pair(pattern=True)
@@ -563,7 +568,8 @@ def test_placement_never_judges_a_set_on_its_first_launch():
     assert pl.replacement_due(a, [b]) and not pl.replacement_due(b, [a]) and not pl.settled
     for ms in (5.6, 5.6):
         a.record_ms(ms)
-    assert a.uses == 4 and not pl.replacement_due(a, [b]) and pl.settled  # past the decision window: it stays
+        b.record_ms(4.9)
+    assert a.uses == 4 and b.uses == 4 and not pl.replacement_due(a, [b]) and pl.settled  # past the decision window: it stays
     pl.replaced[key] = pl.REPLACEMENTS
     a2 = TrajSet(key)
     a2.placement = {"chosen_ms": 5.7}
