@@ -488,7 +488,12 @@ def test_trajectory_kernels_do_not_spill():
     # reloaded inside the step loop's common path — the launch measures 5.5 ms / 0.65 of the roof (round 3, 44 bytes: 5.7 ms)
     assert worst[1]["scratch"] <= 96, worst
     assert all(v["scratch"] == 0 for k, v in ring.items() if "PmsmIfEE" in k)
-    lean32 = {k: v for k, v in res.items() if "sim_ahead_kernel" in k and "IfEEf" in k and "PmsmSat" not in k}
+    # the acrobot instantiations with gym outputs are capped at 256 registers on purpose (kernels.hpp sim_min_waves: two waves per
+    # SIMD with a few spilled registers measured 4.66 ms where 263 registers and one wave measured 6.0): bounded, not zero
+    capped = {k: v for k, v in res.items() if "sim_ahead_kernel" in k and "AcrobotIfEEf" in k and "ELb0ELb0ELb1ELi256EEE" in k}
+    assert capped and all(v["vgpr"] <= 256 for v in capped.values())
+    assert all(v["scratch"] <= 32 for k, v in capped.items() if "AcrobotIfEEfLi0E" in k), capped  # Euler: what default options run
+    lean32 = {k: v for k, v in res.items() if "sim_ahead_kernel" in k and "IfEEf" in k and "PmsmSat" not in k and k not in capped}
     assert lean32 and all(v["scratch"] == 0 for v in lean32.values()), [k for k, v in lean32.items() if v["scratch"]]
 
 
