@@ -290,14 +290,16 @@ template <typename T> struct Pmsm {
     const bool i0 = im >= T(0);
     const bool i1 = (-im - t) >= T(0);
     const bool i2 = (t - im) >= T(0);
-    const T h = T(0.5f), q = T(0.8660254037844386f);
-    const int code = (int(i0) << 2) | (int(i1) << 1) | int(i2);
-    T rr = T(1), ri = T(0);
-    rr = (code == 5 || code == 6) ? h : rr;
-    rr = (code == 2 || code == 1) ? -h : rr;
-    rr = (code == 3) ? T(-1) : rr;
-    ri = (code == 5 || code == 1) ? q : ri;
-    ri = (code == 6 || code == 2) ? -q : ri;
+    const T q = T(0.8660254037844386f);
+    // ROTATION_MAP[code], code = 4 i0 + 2 i1 + i2 (pmsm_env.py:37-43): (1, 0) for codes 0, 3', 4, 7; (1/2, q) for 5; (1/2, -q) for 6;
+    // (-1/2, -q) for 2; (-1/2, q) for 1; (-1, 0) for 3. As arithmetic on the three bits (exact: only 0, 1/2, 1 and q occur), round 5 —
+    // the table walk was eight integer compares and five selects per call, each select behind an `s_nop` (VALU-written SGPR):
+    //   im(rot) = q * (i2 - i1);  |re(rot)| = 1 - |i2 - i1| / 2;  re(rot) < 0  iff  not i0 and (i1 or i2)
+    const T b0 = i0 ? T(1) : T(0), b1 = i1 ? T(1) : T(0), b2 = i2 ? T(1) : T(0);
+    const T d = b2 - b1;
+    const T ri = q * d;
+    const T neg = (T(1) - b0) * ((b1 > b2) ? b1 : b2);
+    const T rr = (T(1) - T(0.5f) * xabs(d)) * (T(1) - T(2) * neg);
     T tr = re * rr - im * ri;
     T ti = re * ri + im * rr;
     const T lim_re = T(2.0 / 3.0);

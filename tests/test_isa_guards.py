@@ -77,7 +77,7 @@ def test_the_guards_reject_deliberately_broken_builds(tmp_path):
     mod = _tool()
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function"]
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wno-unused-function"]
     procs = {}
     for fault in (1, 2, 4):
         obj = str(tmp_path / f"env_tank_fault{fault}.o")

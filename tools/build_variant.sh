@@ -11,7 +11,7 @@ ALL="excenv_api transpose calib env_pendulum env_msd env_cartpole env_acrobot en
 LINK=""
 for o in $ALL; do
   if echo " $OBJS " | grep -q " $o "; then
-    EXTRA=""; case $o in env_acrobot|env_cartpole) EXTRA="-fno-slp-vectorize";; esac
+    EXTRA="-fno-slp-vectorize"
     (cd $SRC && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $EXTRA $FLAGS -c $o.hip -o $TMP/$o.o) &
     LINK="$LINK $TMP/$o.o"
   else
