@@ -378,7 +378,7 @@ def test_pattern_judged_placement_accepts_on_the_absolute_criterion():
 
     block, diag, seen = run([(5.4, 0.76), (5.0, 0.83), (9.9, 0.9)])
     assert diag["candidate_pattern_over_fill"] == [0.76, 0.83] and diag["chosen"] == 1 and block.data_ptr() == seen[1]
-    block, diag, seen = run([(5.0, 0.82)])
-    assert diag["candidate_pattern_over_fill"] == [0.82] and "candidate_ms" not in diag
+    block, diag, seen = run([(5.0, 0.84)])
+    assert diag["candidate_pattern_over_fill"] == [0.84] and "candidate_ms" not in diag
     block, diag, seen = run([(5.5, 0.70), (5.3, 0.74), (5.6, 0.69), (5.4, 0.72), (5.35, 0.73), (5.45, 0.71)])
     assert len(diag["candidate_pattern_over_fill"]) == 6 and diag["chosen"] == 1 and len(set(seen)) == 6
