@@ -269,14 +269,15 @@ def test_pool_wait_stream_orders_the_reuse_behind_a_foreign_reader():
 
 
 def test_placement_settles_and_reports_real_launch_times():
-    """Sets the absolute criterion cannot judge (here: row-major actions) are compared by HIP-event times of their REAL launches —
+    """Sets the absolute criterion cannot judge (here: row-major trajectories) are compared by HIP-event times of their REAL launches —
     the first launch into a set is recorded apart and never a judgement; `trajectory_placement_settled` turns True once every pooled
     set of the shape has a steady time and none is up for replacement. Sets accepted by the absolute criterion are final at once."""
     env, st = _env("pendulum", B=1 << 14)
     K = 32
     g = torch.Generator(device=env.device)
     g.manual_seed(70)
-    acts = torch.rand((env.batch_size, K, 1), generator=g, device=env.device) * 2 - 1  # row-major: no pattern replay
+    acts = torch.rand((env.batch_size, K, 1), generator=g, device=env.device) * 2 - 1
+    env.traj_layout = "env_major"  # the register-ring kernel's write pattern has no replay: judged by real launches
     assert env.trajectory_placement_settled  # nothing pooled yet
     out = env.vmap_sim_ahead(st, acts, env.tau, env.tau)
     seen = [env.trajectory_placement_settled]
