@@ -420,11 +420,8 @@ constexpr int AEM_BLOCK_BYTES = 1024 + 16;  // one LDS-direct load instruction's
 // Pieces per window. 64-byte windows everywhere (same-session sweep over nine workloads, tools/r4_aem_sweep.sh: 32-byte windows
 // cost 3 ... 30 % more: two fabric requests per 64 bytes) except acrobot, whose registers already cap it at two workgroups per
 // CU and which gains 6 % from the smaller LDS footprint.
-// (the 1024-thread form of the small models, round 5: sixteen waves x V x 4 blocks would be 266 KB — 32-byte windows, 133 KB)
-template <class M, int NT = BLOCK> constexpr int aem_np() { return (M::ID == EXCENV_ACROBOT || NT > BLOCK) ? 2 : EXCENV_AEM_NP; }
-template <class M, typename T, int V, int NT = BLOCK> constexpr size_t aem_lds_bytes() {
-  return (size_t)(NT / 64) * V * aem_np<M, NT>() * AEM_BLOCK_BYTES;
-}
+template <class M> constexpr int aem_np() { return M::ID == EXCENV_ACROBOT ? 2 : EXCENV_AEM_NP; }
+template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return (size_t)(BLOCK / 64) * V * aem_np<M>() * AEM_BLOCK_BYTES; }
 
 // LGYM (round 4; lean, V * sizeof(T) == 16, not the look-up model): the reward / terminated / truncated trajectories of
 // core_env.py:490-531 written by the wide kernel itself. PMSM (pmsm_env.py:972-1037): three references per environment, ~40
@@ -457,7 +454,7 @@ template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int 
 __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(const SimArgs<T, M> ka) {
   constexpr int S = M::S, A = M::A, O = M::O;
   extern __shared__ __align__(16) unsigned char excenv_smem[];
-  static_assert(NT == BLOCK || (!GENERAL && !M::HAS_LUT), "wide workgroups: lean instantiations only (plain, with gym outputs, or reading row-major actions)");
+  static_assert(NT == BLOCK || (!GENERAL && !AEM && !M::HAS_LUT), "wide workgroups: lean instantiations only (plain or with gym outputs)");
   constexpr bool ROW_BARRIER = NT > BLOCK;  // wide workgroups: the sixteen waves store every row together
   // GENERAL stays at one environment per lane. Round 4 tried two, each with its own property set (a second Ctx in registers:
   // every leaf may differ per environment, so none can stay in SGPRs — 195 registers, two waves per SIMD): 5.91 ... 6.27 ms for one,
@@ -820,7 +817,7 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
   // ---- AEM: the wave's action windows in LDS (see the comment above the kernel) ----
   constexpr int VW = 16 / (int)sizeof(T);  // elements per 16-byte piece
   constexpr int SP = AEM ? VW / A : 1;     // action rows per piece
-  constexpr int NP = aem_np<M, NT>();      // pieces per window
+  constexpr int NP = aem_np<M>();          // pieces per window
   constexpr int EPI = 64 / NP;             // environments (reader lanes) per load instruction
   static_assert(64 % NP == 0, "a load instruction covers whole windows");
   const unsigned wave = threadIdx.x / 64u, lane64 = threadIdx.x % 64u;

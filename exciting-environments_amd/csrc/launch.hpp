@@ -77,7 +77,7 @@ static inline bool aem_applies(int env_id, bool has_lut, bool general, int A, si
   if (K < 1 || (vmax % A) != 0 || (K * A) % vmax != 0) return false;  // whole 16-byte pieces per row
   if ((B % (64 * vmax)) != 0) return false;  // whole waves: the lanes of a wave fetch action windows for each other
   if ((reinterpret_cast<uintptr_t>(actions) & 15u) != 0) return false;
-  if ((int64_t)1024 * vmax * K * A >= ((int64_t)1 << 32)) return false;  // 32-bit element offsets inside a workgroup (of up to 1024 threads)
+  if ((int64_t)EXCENV_BLOCK * vmax * K * A >= ((int64_t)1 << 32)) return false;             // 32-bit element offsets inside a workgroup
   // only where the batch takes the widest form anyway (launch_sim picks the same way)
   int want = vec_pref > 0 ? vec_pref : (widest_form_pays(B, vmax) ? vmax : 1);
   if (vec_pref == 0 && env_id == EXCENV_ACROBOT && solver != EXCENV_EULER && want > 2) want = 2;
@@ -401,7 +401,7 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
   const int64_t lanes = sc.B / V;
   const dim3 grid((unsigned)((lanes + nt - 1) / nt)), block(nt);
   if constexpr (sim_wide_ok<M, T>(SOLVER)) {
-    if (nt == WIDE_THREADS && !lgym && !aem) {  // the widest lean form in 1024-thread workgroups, one barrier per row (launch_sim decides)
+    if (nt == WIDE_THREADS && !lgym) {  // the widest lean form in 1024-thread workgroups, one barrier per row (launch_sim decides)
       constexpr int VA = 16 / (int)sizeof(T);
       if (ka.straj[0] == nullptr) EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 0, false, false, false, WIDE_THREADS>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
       else EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 1, false, false, false, WIDE_THREADS>), grid, block, (size_t)sc_in.lds_pad, sc.stream, ka);
@@ -427,14 +427,6 @@ template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(
   if constexpr (!M::HAS_LUT && (16 / (int)sizeof(T)) % M::A == 0) {
     if (aem) {  // row-major actions through the per-wave LDS piece ring: V == 16 / sizeof(T) (aem_applies)
       constexpr int VA = 16 / (int)sizeof(T);
-      if constexpr (sim_wide_ok<M, T>(SOLVER)) {
-        if (nt == WIDE_THREADS) {  // the small models' Euler kernels keep their 1024-thread form (32-byte windows: 133 KB of LDS)
-          const size_t wlds = aem_lds_bytes<M, T, VA, WIDE_THREADS>() + (size_t)sc_in.lds_pad;
-          if (ka.straj[0] == nullptr) EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 0, false, true, false, WIDE_THREADS>), grid, block, wlds, sc.stream, ka);
-          else EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 1, false, true, false, WIDE_THREADS>), grid, block, wlds, sc.stream, ka);
-          return;
-        }
-      }
       const size_t lds = aem_lds_bytes<M, T, VA>() + (size_t)sc_in.lds_pad;
       if (ka.straj[0] == nullptr) EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 0, false, true>), grid, block, lds, sc.stream, ka);
       else EXCENV_LAUNCH_DYN((sim_ahead_kernel<M, T, SOLVER, AHEAD, false, VA, 1, false, true>), grid, block, lds, sc.stream, ka);
@@ -710,8 +702,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     if (bytes <= ((size_t)64 << 10)) { ka.row_sync = 2; row_lds = bytes; }
   }
   int nt = BLOCK;
-  static const bool aem_wide = [] { const char* e = std::getenv("EXCENV_AEM_WIDE"); return !(e && e[0] == '0'); }();  // A/B switch
-  if (wide_enabled() && sim_wide_ok<M, T>(sc.solver) && (!lean_gym || sim_wide_gym_ok<M, T>(sc.solver)) && !general && (!aem || aem_wide) && !tiled_a && !tiled_t && V == VMAX &&
+  if (wide_enabled() && sim_wide_ok<M, T>(sc.solver) && (!lean_gym || sim_wide_gym_ok<M, T>(sc.solver)) && !general && !aem && !tiled_a && !tiled_t && V == VMAX &&
       sc.B / V >= WIDE_THREADS * WIDE_MIN_WORKGROUPS)
     nt = WIDE_THREADS;
   {  // element offset of workgroup w's first env in each stream
