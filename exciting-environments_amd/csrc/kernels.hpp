@@ -242,6 +242,42 @@ template <int V> __device__ __forceinline__ void store_flags(uint8_t* p, const u
   }
 }
 
+// NB adjacent flag bytes per lane — the truncated flags of a lane's V environments, TW each, in the lane-major flag layout
+// [row][B][TW] — already packed into dwords: the fewest stores (16 / 12 / 8 / 4 / 2 bytes). p is 4-byte aligned (V * TW bytes per
+// lane with V even), not more: the vector types say so, the global stores of gfx950 take it.
+template <int NB> __device__ __forceinline__ void store_flag_bytes(uint8_t* p, const uint32_t (&w)[(NB + 3) / 4]) {
+  static_assert(NB % 2 == 0, "an even number of environments per lane");
+  typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
+  typedef uint32_t U3 __attribute__((ext_vector_type(3), aligned(4)));
+  typedef uint32_t U2 __attribute__((ext_vector_type(2), aligned(4)));
+  constexpr int NW = NB / 4;
+  constexpr int Q = NW / 4 * 4;
+#pragma unroll
+  for (int j = 0; j < Q; j += 4) {
+    U4 v;
+    v[0] = w[j]; v[1] = w[j + 1]; v[2] = w[j + 2]; v[3] = w[j + 3];
+    *reinterpret_cast<U4*>(p + 4 * j) = v;
+  }
+  if constexpr (NW - Q == 3) {
+    U3 v;
+    v[0] = w[Q]; v[1] = w[Q + 1]; v[2] = w[Q + 2];
+    *reinterpret_cast<U3*>(p + 4 * Q) = v;
+  } else if constexpr (NW - Q == 2) {
+    U2 v;
+    v[0] = w[Q]; v[1] = w[Q + 1];
+    *reinterpret_cast<U2*>(p + 4 * Q) = v;
+  } else if constexpr (NW - Q == 1) {
+    *reinterpret_cast<uint32_t*>(p + 4 * Q) = w[Q];
+  }
+  if constexpr (NB % 4 == 2) *reinterpret_cast<uint16_t*>(p + 4 * NW) = (uint16_t)w[NW];
+}
+template <int K> struct IntC { static constexpr int value = K; };
+// f(IntC<n>) for the wave-uniform n in [K, KMAX] (a chain of scalar branches; n outside the range: nothing)
+template <int K, int KMAX, class F> __device__ __forceinline__ void dispatch_count(int n, F&& f) {
+  if (n == K) f(IntC<K>{});
+  else if constexpr (K < KMAX) dispatch_count<K + 1, KMAX>(n, f);
+}
+
 // ---- gym outputs of one saved state (generate_reward / generate_terminated / generate_truncated) ----------------
 // `ob` is the observation row of `st` (without control columns); `ref[j]` the physical reference of control column j.
 // Stores through the three element pointers (reward, terminated: one element; truncated: TW flags, stride t_sc).
@@ -539,6 +575,25 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
       }
     }
   }
+  // ... and the control columns' share of a row's packed truncated flags (lane-major flag layout [row][B][TW]: the V * TW bytes
+  // of a lane's environments are adjacent; byte v * TW + O + j is control column j of environment v), once per trajectory
+  constexpr int GP_NW = (LGYM && !M::IS_PMSM) ? (V * (O + NCM) + 3) / 4 : 1;
+  uint32_t gp_w[GP_NW];
+  if constexpr (LGYM && !M::IS_PMSM && M::ID != EXCENV_FLUID_TANK) {
+#pragma unroll
+    for (int i = 0; i < GP_NW; ++i) gp_w[i] = 0u;
+    dispatch_count<0, NCM>(ka.n_control, [&](auto tag) {
+      constexpr int NC = decltype(tag)::value, TWc = O + NC;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          const int b = v * TWc + O + j;
+          gp_w[b >> 2] |= (uint32_t)gp_f[v][j] << ((b & 3) * 8);
+        }
+      }
+    });
+  }
   // LGYM, PMSM: the references of the controlled fields among i_d (3), i_q (4), torque (5), per environment of the lane
   T g_id[V], g_iq[V], g_tq[V];
   bool has_id = false, has_iq = false, has_tq = false;
@@ -712,7 +767,6 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
     }
     if constexpr (LGYM && !M::IS_PMSM) {  // generate_reward / generate_truncated / generate_terminated of the other models, V wide
       const int64_t e0 = blk0 + lane_env;
-      uint8_t* trow = ka.truncated + n * ka.t_sk + e0;
       T rew[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) rew[v] = T(0);
@@ -740,25 +794,29 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
         }
       }
       uint8_t fl[V];
-      if constexpr (M::ID == EXCENV_FLUID_TANK) {  // fluid_tank_env.py:325-333: constants
+      if constexpr (M::ID == EXCENV_FLUID_TANK) {  // fluid_tank_env.py:325-333: constants (TW = 1)
 #pragma unroll
         for (int v = 0; v < V; ++v) fl[v] = 0;
-        store_flags<V>(trow, fl);
+        store_flags<V>(ka.truncated + n * ka.t_sk + e0, fl);
       } else {
+        // |obs| > 1 per observation column + the control columns' constant flags: the V * TW bytes of the lane's environments are
+        // adjacent in the row — ONE 16-byte store for pendulum [theta] instead of four 4-byte ones (round 5; the store
+        // instructions of a gym launch were 2.0 ... 2.5 x the plain launch's for 1.2 ... 1.4 x its bytes)
+        dispatch_count<0, NCM>(ka.n_control, [&](auto tag) {
+          constexpr int NC = decltype(tag)::value, TWc = O + NC, NB = V * TWc, NW = (NB + 3) / 4;
+          uint32_t w[NW];
 #pragma unroll
-        for (int q = 0; q < O; ++q) {
+          for (int i = 0; i < NW; ++i) w[i] = gp_w[i];
 #pragma unroll
-          for (int v = 0; v < V; ++v) fl[v] = xabs(ob[v][q]) > T(1);
-          store_flags<V>(trow + q * ka.t_sc, fl);
-        }
+          for (int v = 0; v < V; ++v) {
 #pragma unroll
-        for (int j = 0; j < NCM; ++j) {
-          if (j < ka.n_control) {  // the control columns' flags do not change along the trajectory
-#pragma unroll
-            for (int v = 0; v < V; ++v) fl[v] = gp_f[v][j];
-            store_flags<V>(trow + (O + j) * ka.t_sc, fl);
+            for (int q = 0; q < O; ++q) {
+              const int b = v * TWc + q;
+              w[b >> 2] |= (xabs(ob[v][q]) > T(1)) ? (1u << ((b & 3) * 8)) : 0u;
+            }
           }
-        }
+          store_flag_bytes<NB>(ka.truncated + n * ka.t_sk + e0 * TWc, w);
+        });
 #pragma unroll
         for (int v = 0; v < V; ++v) fl[v] = rew[v] == T(0);  // generate_terminated: reward == 0
       }
@@ -828,7 +886,9 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
   // loader side: lane t serves reader lane slot t / NP of the instruction's EPI, piece t % NP
   const unsigned ld_piece = lane64 % NP;
   const uint64_t ld_lane_off = AEM ? ((uint64_t)(wave * 64u + lane64 / NP) * V) * (uint64_t)ka.a_sb : 0;  // elements, before (i, v)
-  const int64_t n_pieces = AEM ? (ka.K * A) / VW : 0;  // pieces per environment row (host: K * A % VW == 0)
+  // pieces per environment row (host: K * A % VW == 0, and K * A < 2^23: the window bookkeeping below is unsigned 32-bit scalar
+  // arithmetic — as int64_t every division by a power of two was a 64-bit shift with a sign fix-up, per slot and step)
+  const int32_t n_pieces = AEM ? (int32_t)((ka.K * A) / VW) : 0;
   constexpr int NSTORE = O + ((STATES != 0) ? S : 0);   // trajectory stores per saved row: issued between a fill and its first read
   // Sector-aligned windows (round 5). A window is NP pieces = 64 bytes and one fabric request — if it does not straddle two
   // 64-byte sectors of memory. Rows of K * A * sizeof(T) bytes start on 16-byte boundaries only (PMSM, K = 100: 800 bytes, every
@@ -841,17 +901,17 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
   // scheme), so each slot keeps its own wave-uniform window count and refills when ITS window ends.
   const bool aem_aligned = AEM && ((n_pieces * V) % NP) == 0;
   unsigned aem_ph[V];
-  int64_t w_hi[V];  // highest window requested so far, per slot (wave-uniform)
+  int32_t w_hi[V];  // highest window requested so far, per slot (wave-uniform)
 #pragma unroll
   for (int v = 0; v < V; ++v) {
-    aem_ph[v] = aem_aligned ? (unsigned)((((uintptr_t)a_blk >> 4) + (uint64_t)v * (uint64_t)n_pieces) % NP) : 0u;
+    aem_ph[v] = aem_aligned ? (unsigned)((((uintptr_t)a_blk >> 4) + (uint64_t)v * (uint64_t)(uint32_t)n_pieces) % NP) : 0u;
     w_hi[v] = -1;
   }
-  auto dma_window = [&](int v, int64_t w) __attribute__((always_inline)) {  // v: compile-time constant at every call
+  auto dma_window = [&](int v, int32_t w) __attribute__((always_inline)) {  // v: compile-time constant at every call
     if constexpr (AEM) {
-      int64_t pc = w * NP + ld_piece - (int64_t)aem_ph[v];
+      int32_t pc = w * NP + (int32_t)ld_piece - (int32_t)aem_ph[v];
       pc = pc < 0 ? 0 : (pc < n_pieces ? pc : n_pieces - 1);  // in front of the row / behind it: a piece of the row again (never read)
-      const T* lane_src = a_blk + ld_lane_off + pc * VW;
+      const T* lane_src = a_blk + ld_lane_off + (int64_t)pc * VW;
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         // Inline assembly, not __builtin_amdgcn_global_load_lds: the compiler treats an LDS-direct load as a FLAT access and puts
@@ -877,16 +937,17 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
   };
   auto load_action = [&](int64_t krow, T (&dst)[A][V]) __attribute__((always_inline)) {
     if constexpr (AEM) {
-      const int64_t j = krow / SP;                  // the row's piece of its environment's row
-      const unsigned rs = (unsigned)(krow % SP);    // the row inside that piece
-      int64_t w[V];
+      const uint32_t kr = (uint32_t)krow;         // 0 <= krow < K < 2^23
+      const int32_t j = (int32_t)(kr / (uint32_t)SP);  // the row's piece of its environment's row
+      const unsigned rs = kr % (uint32_t)SP;      // the row inside that piece
+      int32_t w[V];
       unsigned pos[V];
       bool opens = false;
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        const int64_t q = j + (int64_t)aem_ph[v];
-        w[v] = q / NP;
-        pos[v] = (unsigned)(q % NP);
+        const uint32_t q = (uint32_t)j + aem_ph[v];
+        w[v] = (int32_t)(q / (uint32_t)NP);
+        pos[v] = q % (uint32_t)NP;
         opens = opens || (pos[v] == 0 && rs == 0);
       }
       // first row of a window (of any slot) that was requested one row earlier: everything but the trajectory stores issued since
@@ -911,7 +972,7 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         if (pos[v] == NP - 1 && rs == SP - 1 && subn == ka.substeps - 1 && w[v] + 1 > w_hi[v] &&
-            (w[v] + 1) * NP - (int64_t)aem_ph[v] < n_pieces) {
+            (w[v] + 1) * NP - (int32_t)aem_ph[v] < n_pieces) {
           if (!drained) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           drained = true;
           dma_window(v, w[v] + 1);

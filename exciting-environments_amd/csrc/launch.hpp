@@ -389,8 +389,11 @@ template <class M, typename T> constexpr bool sim_wide_ok(int solver) {
          (M::ID == EXCENV_PENDULUM || M::ID == EXCENV_MASS_SPRING_DAMPER || (M::ID == EXCENV_FLUID_TANK && sizeof(T) == 4));
 }
 
-// with the gym outputs' code the pendulum instantiations need 128 ... 145 registers: they would spill under the 1024-thread bound
-template <class M, typename T> constexpr bool sim_wide_gym_ok(int solver) { return sim_wide_ok<M, T>(solver) && M::ID != EXCENV_PENDULUM; }
+// with the gym outputs' code the fp64 pendulum instantiations need 146 ... 150 registers: they would spill under the 1024-thread bound
+// (fp32: 118 ... 123 since round 5 — wide like its plain launch: 2.43 -> 2.2 ms for the gym trajectories of B = 2^22, K = 100)
+template <class M, typename T> constexpr bool sim_wide_gym_ok(int solver) {
+  return sim_wide_ok<M, T>(solver) && (M::ID != EXCENV_PENDULUM || sizeof(T) == 4);
+}
 
 template <class M, typename T, int SOLVER, bool AHEAD> static void launch_sim_v(const SimCall& sc_in, const SimArgs<T, M>& ka_in,
                                                                                  bool general, int V, bool aem = false, bool lgym = false,
@@ -557,7 +560,7 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
       ka.t_sb = (N + 1) * TW; ka.t_sk = TW; ka.t_sc = 1;
     } else {
       ka.g_sb = 1; ka.g_sk = sc.B;
-      ka.t_sb = 1; ka.t_sk = TW * sc.B; ka.t_sc = sc.B;
+      ka.t_sb = TW; ka.t_sk = TW * sc.B; ka.t_sc = 1;  // lane-major flags: [row][B][TW], an environment's flags adjacent (ABI 7)
     }
   }
   for (int j = 0; j < ka.n_control; ++j) {
@@ -667,7 +670,12 @@ template <class M, typename T> static int launch_sim(const SimCall& sc) {
     // floor meet (2.7 / 2.8 ms) and what counts is how well they overlap: two environments per lane (116 registers, four waves
     // per SIMD) instead of four (186, two waves). Same-buffers A/B: Euler 3.555 -> 3.157 ms (0.59 -> 0.66 of the roof), RK4 4.457 ->
     // 4.010, Tsit5 5.435 -> 4.784; with full outputs four stay faster (RK4 5.64 vs 6.19, Tsit5 6.25 vs 6.37).
-    if (sc.vec_pref == 0 && M::IS_PMSM && !M::HAS_LUT && sizeof(T) == 4 && ka.straj[0] == nullptr && !aem && !lean_gym && want > 2) want = 2;
+    // Round 5, after the instruction diet (same-buffers A/B, one / two / four per lane): Euler 3.34 / 3.49 / 3.46 ms — one; RK4 3.79 /
+    // 3.72 / 4.04 and Tsit5 4.32 / 4.19 / 4.73 — two.
+    if (sc.vec_pref == 0 && M::IS_PMSM && !M::HAS_LUT && sizeof(T) == 4 && ka.straj[0] == nullptr && !aem && !lean_gym) {
+      const int cap = (sc.solver == EXCENV_EULER) ? 1 : 2;
+      if (want > cap) want = cap;
+    }
     // cart-pole RK4 / Tsit5 and pendulum Tsit5 in fp32: the same trade (registers for a resident wave) — same-buffers A/B with two
     // instead of four environments per lane: cart-pole RK4 4.646 -> 4.323 ms, Tsit5 7.046 -> 6.091, pendulum Tsit5 2.637 -> 2.477
     // (pendulum RK4, mass-spring-damper, tank: four stay faster or equal)
@@ -794,7 +802,7 @@ template <class M, typename T> static int launch_traj_gym(const TrajGymCall& gc)
     ka.t_sb = gc.rows * TW; ka.t_sk = TW; ka.t_sc = 1;
   } else {
     ka.g_sb = 1; ka.g_sk = gc.B;
-    ka.t_sb = 1; ka.t_sk = TW * gc.B; ka.t_sc = gc.B;
+    ka.t_sb = TW; ka.t_sk = TW * gc.B; ka.t_sc = 1;  // [row][B][TW]
   }
   if (gc.B == 0 || gc.rows == 0) return EXCENV_OK;
   ka.fast_is_env = (gc.s_sb == 1 || gc.rows == 1) ? 1 : 0;  // lanes run along the contiguous index of the state arrays

@@ -17,7 +17,7 @@ LAYOUT_ENV_MAJOR, LAYOUT_LANE_MAJOR, LAYOUT_TILED = 0, 1, 2
 TILE = 1024  # EXCENV_TILE
 SEM_STEP, SEM_AHEAD = 0, 1
 F32, F64 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _LIB_PATH = os.environ.get(  # EXCENV_HIP_LIB: A/B-test another build of the same library (tuning experiments)
     "EXCENV_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libexcenv_hip.so"))

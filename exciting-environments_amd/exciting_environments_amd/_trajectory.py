@@ -90,8 +90,8 @@ class TrajectoryLaunchMixin:
             if t_layout == _native.LAYOUT_LANE_MAJOR:
                 rew = torch.empty((N, B), dtype=self.dtype, device=self.device)
                 term = torch.empty((N, B), dtype=torch.bool, device=self.device)
-                trunc = torch.empty((N + 1, TW, B), dtype=torch.bool, device=self.device)
-                gym_out = (rew.t()[..., None], trunc.permute(2, 0, 1), term.t()[..., None])
+                trunc = torch.empty((N + 1, B, TW), dtype=torch.bool, device=self.device)
+                gym_out = (rew.t()[..., None], trunc.permute(1, 0, 2), term.t()[..., None])
             else:
                 rew = torch.empty((B, N, 1), dtype=self.dtype, device=self.device)
                 term = torch.empty((B, N, 1), dtype=torch.bool, device=self.device)
@@ -197,12 +197,12 @@ class TrajectoryLaunchMixin:
         st_in_ptrs = _native._ptrs(st_in)
 
         gym_out = gym_ref = None
-        if want_gym:  # excenv_traj_gym_t, lane-major: reward / terminated [N][B], truncated [N + 1][TW][B]
+        if want_gym:  # excenv_traj_gym_t, lane-major: reward / terminated [N][B], truncated [N + 1][B][TW]
             TW = _native.truncated_width(self.ENV_ID, len(self.control_state))
             rew = torch.empty((N, B), dtype=dt, device=dev)
             term = torch.empty((N, B), dtype=torch.bool, device=dev)
-            trunc = torch.empty((N + 1, TW, B), dtype=torch.bool, device=dev)
-            gym_out = (rew.t()[..., None], trunc.permute(2, 0, 1), term.t()[..., None])
+            trunc = torch.empty((N + 1, B, TW), dtype=torch.bool, device=dev)
+            gym_out = (rew.t()[..., None], trunc.permute(1, 0, 2), term.t()[..., None])
             gym_struct = _native.TrajGym(rew.data_ptr(), term.data_ptr(), trunc.data_ptr())
             gym_ref = ctypes.byref(gym_struct)
         done = (lambda *r: r + (gym_out,)) if want_gym else (lambda *r: r)

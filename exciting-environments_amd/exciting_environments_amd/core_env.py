@@ -717,8 +717,8 @@ class CoreEnvironment(TrajectoryLaunchMixin, ABC):
         if lane_major:  # outputs as [B, ., .] views over lane-major memory, like the trajectories themselves
             rew_buf = torch.empty((max(N, 0), B), dtype=self.dtype, device=self.device)
             term_buf = torch.empty((max(N, 0), B), dtype=torch.bool, device=self.device)
-            trunc_buf = torch.empty((rows, TW, B), dtype=torch.bool, device=self.device)
-            out = (rew_buf.t()[..., None], trunc_buf.permute(2, 0, 1), term_buf.t()[..., None])
+            trunc_buf = torch.empty((rows, B, TW), dtype=torch.bool, device=self.device)
+            out = (rew_buf.t()[..., None], trunc_buf.permute(1, 0, 2), term_buf.t()[..., None])
             layout = _native.LAYOUT_LANE_MAJOR
         else:
             rew_buf = torch.empty((B, max(N, 0), 1), dtype=self.dtype, device=self.device)

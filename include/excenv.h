@@ -36,8 +36,11 @@ extern "C" {
  * 5: v4 + excenv_stream_pattern (addition only)
  * 6: v5 + excenv_launch_opts_t.flags (the former `reserved` field; 0 keeps the old meaning); excenv_sim_ahead reads row-major
  *    actions inside the lane-major trajectory kernel (no workspace needed for that combination); additions:
- *    excenv_sim_ahead_fuses_actions, excenv_last_launch, excenv_allgather */
-#define EXCENV_ABI_VERSION 6
+ *    excenv_sim_ahead_fuses_actions, excenv_last_launch, excenv_allgather
+ * 7: the lane-major truncated-flag trajectory is [row][B][flag] (an environment's flags adjacent; was [row][flag][B]):
+ *    excenv_traj_gym_t.truncated of excenv_sim_ahead and the `truncated` output of excenv_rew_trunc_term. Every signature
+ *    is unchanged; the env-major layout [B][row][flag] — the reference's — is untouched */
+#define EXCENV_ABI_VERSION 7
 
 /* Environment ids. Field orders follow the reference dataclasses. */
 typedef enum {
@@ -152,7 +155,9 @@ typedef struct {
  *   reward     : N rows (saved rows 1..N) of one value per env, working dtype
  *   terminated : N rows of one byte (0/1) per env
  *   truncated  : N+1 rows (saved rows 0..N) of excenv_truncated_width() bytes per env
- * in the trajectory layout of the call: lane-major [row][flag][B] / env-major [B][row][flag] (tiled: unsupported). */
+ * in the trajectory layout of the call: env-major reward / terminated [B][row], truncated [B][row][flag]; lane-major reward /
+ * terminated [row][B], truncated [row][B][flag] (the flags of an environment adjacent: a lane of the trajectory kernel writes
+ * the flags of its environments with one or two stores per row). Tiled: unsupported. */
 typedef struct {
   void* reward;
   uint8_t* terminated;
@@ -253,7 +258,8 @@ int excenv_transpose(int dtype, int64_t M, int64_t N, const void* in, void* out,
  *   control    : reference[j] is the base of the reference values of field control_idx[j]; ref_strides[2j], [2j+1] are its
  *                element strides (env, row) — (1, 0) for a reference that is constant along the trajectory; NULL = (1, 0)
  *   reward     : rows-1 values per env (rows 1..), terminated: rows-1 bytes, truncated: rows x excenv_truncated_width bytes,
- *                laid out as `out_layout` (EXCENV_LAYOUT_ENV_MAJOR [B][row][flag] or EXCENV_LAYOUT_LANE_MAJOR [row][flag][B]) */
+ *                laid out as `out_layout` (EXCENV_LAYOUT_ENV_MAJOR [B][row][flag] or EXCENV_LAYOUT_LANE_MAJOR: reward / terminated
+ *                [row][B], truncated [row][B][flag]) */
 int excenv_rew_trunc_term(int env, int dtype, int64_t B, int64_t rows, const excenv_props_t* props,
                           const excenv_control_t* control, const int64_t* ref_strides, const void* const* state_traj,
                           int64_t state_env_stride, int64_t state_row_stride, void* reward, uint8_t* terminated,

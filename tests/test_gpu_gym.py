@@ -548,12 +548,12 @@ def test_gym_trajectories_with_a_misaligned_array_take_the_general_kernel(which)
         ref = buf(B, o["reference"])
         ref.copy_((torch.rand(B, generator=g) * 6 - 3).to(dev))
         acts = torch.as_tensor(rng.uniform(-1, 1, (K, 1, B)).astype(np.float32), device=dev) if not results else results[0]["acts"]
-        obs = buf((K + 1) * 3 * B, o["obs"])
+        obs = buf((K + 1) * 4 * B, o["obs"])  # O = 3 observation columns + the control column
         straj = [buf((K + 1) * B, o["state_traj"]) for _ in range(2)]
         last = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(2)]
         rew = torch.zeros((K, B), dtype=torch.float32, device=dev)
         term = torch.zeros((K, B), dtype=torch.bool, device=dev)
-        trunc = torch.zeros((K + 1, 3, B), dtype=torch.bool, device=dev)
+        trunc = torch.zeros((K + 1, B, 4), dtype=torch.bool, device=dev)  # excenv_truncated_width(pendulum, 1) = 4 flags per environment
         control = _native.make_control([0], [ref])
         _native.sim_ahead(env.ENV_ID, env._solver.id, torch.float32, B, K, 1, props, control, env.tau, env.tau, st_in, acts,
                           _native.LAYOUT_LANE_MAJOR, obs, straj, _native.LAYOUT_LANE_MAJOR, last, _native.SEM_AHEAD, None,

@@ -80,6 +80,9 @@ def test_one_environment_per_lane_has_the_bits_of_four(env_name, dtype, solver, 
     st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=83)
     acts = env.new_actions_buffer(K)
     acts.copy_(torch.as_tensor(np.random.default_rng(84).uniform(-1, 1, (B, K, env.action_dim)).astype(NP_DTYPE[dtype]), device=env.device))
+    # the widest form asked for explicitly: the default rules may pick one environment per lane themselves (PMSM Euler observations
+    # only, since round 5)
+    env.launch_opts = _native.launch_opts(envs_per_lane=4 if dtype is torch.float32 else 2)
     wide = env.vmap_sim_ahead(to_state(env, st), acts, env.tau, env.tau)
     torch.cuda.synchronize()
     assert "V=1" not in _native.last_launch()

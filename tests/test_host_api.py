@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.library_path())
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"libexcenv_hip.so does not export {sym}"
-    assert _native.lib().excenv_abi_version() == 6
+    assert _native.lib().excenv_abi_version() == 7
 
 
 def test_env_dims_and_algorithmic_bytes():

@@ -27,8 +27,11 @@ ap.add_argument("names", nargs="*")
 a = ap.parse_args()
 
 base_path = _native.library_path()
-# a name of the form vec=N is not another library but the in-tree one with N environments per lane (launch option)
-libs = [("in-tree", base_path)] + [(n, base_path if n.startswith("vec=") else os.path.join(ROOT, "ab_libs", f"libexcenv_{n}.so")) for n in a.names]
+# a name of the form vec=N is not another library but the in-tree one with N environments per lane (launch option); env:NAME=VALUE is
+# the in-tree library with that environment variable set for its launches (switches the library reads per call)
+inline = lambda n: n.startswith("vec=") or n.startswith("env:")
+libs = [("in-tree", base_path)] + [(n, base_path if inline(n) else os.path.join(ROOT, "ab_libs", f"libexcenv_{n}.so")) for n in a.names]
+env_names = {n[4:].split("=", 1)[0] for n in a.names if n.startswith("env:")}
 
 
 def use(path):
@@ -64,6 +67,10 @@ res = {n: [] for n, _ in libs}
 for r in range(a.rounds):
     for n, p in libs:
         use(p)
+        for e in env_names:
+            os.environ.pop(e, None)
+        if n.startswith("env:"):
+            os.environ[n[4:].split("=", 1)[0]] = n[4:].split("=", 1)[1]
         env.launch_opts = _native.launch_opts(envs_per_lane=int(n[4:])) if n.startswith("vec=") else None
         for _ in range(4):
             out = call()
@@ -78,9 +85,9 @@ for r in range(a.rounds):
         ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.calls)]
         res[n].append(ms)
         even, odd = ms[0::2], ms[1::2]
-        print(f"round {r} {n:10s} launch {_native.last_launch():28s} mean {sum(ms) / len(ms):.3f}  sets {sum(even) / len(even):.3f} / {sum(odd) / len(odd):.3f}  min {min(ms):.3f}",
+        print(f"round {r} {n:18s} launch {_native.last_launch():28s} mean {sum(ms) / len(ms):.3f}  sets {sum(even) / len(even):.3f} / {sum(odd) / len(odd):.3f}  min {min(ms):.3f}",
               flush=True)
 print()
 for n, _ in libs:
     allms = [x for ms in res[n] for x in ms]
-    print(f"{n:10s} mean {sum(allms) / len(allms):.3f} ms  min {min(allms):.3f}")
+    print(f"{n:18s} mean {sum(allms) / len(allms):.3f} ms  min {min(allms):.3f}")
