@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Register-window form of the row-major action read (kernels.hpp, AEM == 2) in the 1024-thread workgroups: same bits as the
-lane-major call at a batch that takes the wide form? (GPU box; EXCENV_AEM_REG is read per call)"""
+"""Goes with register_windows.patch (a measured-and-removed experiment; apply the patch and rebuild first): the
+register-window form of the row-major action read (kernels.hpp, AEM == 2), narrow and in 1024-thread workgroups — same bits as the
+lane-major call at a batch that takes the wide form, and how fast? (GPU box; the patched library reads EXCENV_AEM_REG per call)"""
 import os
 import sys
 import time
