@@ -243,13 +243,29 @@ template <int V> __device__ __forceinline__ void store_flags(uint8_t* p, const u
 }
 
 // NB adjacent flag bytes per lane — the truncated flags of a lane's V environments, TW each, in the lane-major flag layout
-// [row][B][TW] — already packed into dwords: the fewest stores (16 / 12 / 8 / 4 / 2 bytes). p is 4-byte aligned (V * TW bytes per
-// lane with V even), not more: the vector types say so, the global stores of gfx950 take it.
-template <int NB> __device__ __forceinline__ void store_flag_bytes(uint8_t* p, const uint32_t (&w)[(NB + 3) / 4]) {
-  static_assert(NB % 2 == 0, "an even number of environments per lane");
+// [row][B][TW] — already packed into dwords: the fewest stores (16 / 12 / 8 / 4 / 2 bytes). p is aligned to NB's largest power-of-two
+// factor up to 4 (V * TW bytes per lane: 4 with four environments per lane, 2 with two and an odd TW), not more: the types say so,
+// the global stores of gfx950 take it.
+template <int AL> struct FlagWords;
+template <> struct FlagWords<4> {
   typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
   typedef uint32_t U3 __attribute__((ext_vector_type(3), aligned(4)));
   typedef uint32_t U2 __attribute__((ext_vector_type(2), aligned(4)));
+  typedef uint32_t U1 __attribute__((aligned(4)));
+};
+template <> struct FlagWords<2> {
+  typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(2)));
+  typedef uint32_t U3 __attribute__((ext_vector_type(3), aligned(2)));
+  typedef uint32_t U2 __attribute__((ext_vector_type(2), aligned(2)));
+  typedef uint32_t U1 __attribute__((aligned(2)));
+};
+template <int NB> __device__ __forceinline__ void store_flag_bytes(uint8_t* p, const uint32_t (&w)[(NB + 3) / 4]) {
+  static_assert(NB % 2 == 0, "an even number of environments per lane");
+  typedef FlagWords<(NB % 4 == 0) ? 4 : 2> FW;
+  typedef typename FW::U4 U4;
+  typedef typename FW::U3 U3;
+  typedef typename FW::U2 U2;
+  typedef typename FW::U1 U1;
   constexpr int NW = NB / 4;
   constexpr int Q = NW / 4 * 4;
 #pragma unroll
@@ -267,7 +283,7 @@ template <int NB> __device__ __forceinline__ void store_flag_bytes(uint8_t* p, c
     v[0] = w[Q]; v[1] = w[Q + 1];
     *reinterpret_cast<U2*>(p + 4 * Q) = v;
   } else if constexpr (NW - Q == 1) {
-    *reinterpret_cast<uint32_t*>(p + 4 * Q) = w[Q];
+    *reinterpret_cast<U1*>(p + 4 * Q) = w[Q];
   }
   if constexpr (NB % 4 == 2) *reinterpret_cast<uint16_t*>(p + 4 * NW) = (uint16_t)w[NW];
 }
@@ -478,13 +494,17 @@ template <class M, typename T, int V> constexpr size_t aem_lds_bytes() { return 
 // against a few registers: when the math primitives were restructured in round 5 these instantiations went from 205 ... 254 to
 // 259 ... 294 registers — one wave per SIMD instead of two (acrobot's gym trajectories: 4.9 -> 6.0 ms). Everything else keeps the
 // compiler's choice (the fp64 RK kernels of the four-leaf models and the look-up model need more than 256).
-template <class M, typename T, bool GENERAL, bool AEM, bool LGYM, int STATES> constexpr int sim_min_waves() {
+// The Euler kernels of cart-pole and acrobot with gym outputs (192 registers with the packed flags): neither HBM nor the vector
+// units are saturated at two waves per SIMD (0.60 … 0.62 of the roof); capped at 168 registers a third wave is resident, at the
+// price of 48 … 128 spilled bytes: cart-pole 4.72 -> 4.56 ms, acrobot 4.81 -> 4.68 (B = 2^22, K = 100, two runs each).
+template <class M, typename T, bool GENERAL, bool AEM, bool LGYM, int STATES, int SOLVER = -1> constexpr int sim_min_waves() {
+  if (LGYM && (M::ID == EXCENV_ACROBOT || M::ID == EXCENV_CART_POLE) && sizeof(T) == 4 && SOLVER == EXCENV_EULER) return 3;
   if (LGYM && M::ID == EXCENV_ACROBOT && sizeof(T) == 4) return 2;
   if (GENERAL && M::ID == EXCENV_PENDULUM && sizeof(T) == 8) return 2;
   if (AEM && M::IS_PMSM && !M::HAS_LUT && sizeof(T) == 8 && STATES == 0) return 2;
   return 1;
 }
-#define EXCENV_SIM_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(sim_min_waves<M, T, GENERAL, AEM, LGYM, STATES>())))
+#define EXCENV_SIM_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(sim_min_waves<M, T, GENERAL, AEM, LGYM, STATES, SOLVER>())))
 template <class M, typename T, int SOLVER, bool AHEAD, bool GENERAL, int V, int STATES, bool LUT_LDS = false, bool AEM = false, bool LGYM = false,
           int NT = BLOCK>
 __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(const SimArgs<T, M> ka) {

@@ -492,7 +492,11 @@ def test_trajectory_kernels_do_not_spill():
     # SIMD with a few spilled registers measured 4.66 ms where 263 registers and one wave measured 6.0): bounded, not zero
     capped = {k: v for k, v in res.items() if "sim_ahead_kernel" in k and "AcrobotIfEEf" in k and "ELb0ELb0ELb1ELi256EEE" in k}
     assert capped and all(v["vgpr"] <= 256 for v in capped.values())
-    assert all(v["scratch"] <= 32 for k, v in capped.items() if "AcrobotIfEEfLi0E" in k), capped  # Euler: what default options run
+    # ... and the Euler instantiations of cart-pole and acrobot with gym outputs at 168 (a third wave per SIMD, measured 3 % faster
+    # with 48 ... 128 spilled bytes than two waves without): what default options run
+    capped.update({k: v for k, v in res.items() if "sim_ahead_kernel" in k and "CartPoleIfEEfLi0E" in k and "ELb0ELb0ELb1ELi256EEE" in k})
+    euler = {k: v for k, v in capped.items() if "AcrobotIfEEfLi0E" in k or "CartPoleIfEEfLi0E" in k}
+    assert len(euler) == 8 and all(v["vgpr"] <= 168 and v["scratch"] <= 160 for v in euler.values()), euler
     lean32 = {k: v for k, v in res.items() if "sim_ahead_kernel" in k and "IfEEf" in k and "PmsmSat" not in k and k not in capped}
     assert lean32 and all(v["scratch"] == 0 for v in lean32.values()), [k for k, v in lean32.items() if v["scratch"]]
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """What do the fused reward / terminated / truncated trajectories (vmap_sim_ahead(..., return_rew_trunc_term=True),
 core_env.py:490-531) cost on top of the plain trajectory launch? B = 2^22, K = 100, lane-major buffers, fp32 Euler.
-PMSM: the wide lean kernel writes them itself (round 4, LGYM); the other models take the general instantiation."""
+Per model three launches: plain, with the gym outputs from the wide lean kernel (LGYM, all six models since round 4), and the same with
+one environment per lane (the general instantiation). tools/profile_gym.sh is the profiled version of the first two."""
 import os
 import sys
 import time
