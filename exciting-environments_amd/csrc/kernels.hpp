@@ -955,49 +955,68 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
       }
     }
   };
+  int32_t pc_j = -1, pc_w[V];       // the piece the cached bookkeeping belongs to; its window per slot (all wave-uniform)
+  unsigned pc_off[V];               // byte offset of that piece inside the slot's window
+  uint32_t last_mask = 0u;          // slots whose cached piece is the last of a window with a successor to request
+  bool fill_pending = false;        // a window was requested and no counted wait has run since
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    pc_w[v] = 0;
+    pc_off[v] = 0u;
+  }
   auto load_action = [&](int64_t krow, T (&dst)[A][V]) __attribute__((always_inline)) {
     if constexpr (AEM) {
-      const uint32_t kr = (uint32_t)krow;         // 0 <= krow < K < 2^23
+      // Bookkeeping once per PIECE (SP rows), not per row (round 5: per row and slot it was ~110 scalar instructions per wave-step —
+      // more issue slots than the fluid tank's whole step; the waves of these kernels are bound by how many instructions of any
+      // kind they issue): which window and which position a slot's piece has, and whether it is the last piece of its window.
+      const uint32_t kr = (uint32_t)krow;              // 0 <= krow < K < 2^23
       const int32_t j = (int32_t)(kr / (uint32_t)SP);  // the row's piece of its environment's row
-      const unsigned rs = kr % (uint32_t)SP;      // the row inside that piece
-      int32_t w[V];
-      unsigned pos[V];
-      bool opens = false;
+      const unsigned rs = kr % (uint32_t)SP;           // the row inside that piece
+      const bool newp = j != pc_j;
+      // first row of a piece after a fill was requested (one row earlier, behind the last row of the piece before): everything but
+      // the trajectory stores issued since must be back (vmcnt retires in issue order: with exactly NSTORE vector-memory
+      // instructions behind the fill, vmcnt(NSTORE) waits for the fill and for nothing younger — fills of other slots issued
+      // behind it only make the wait stricter; FEWER than NSTORE behind it and the wait would prove nothing — tools/isa_guards.py
+      // counts them on every path of the built code). expcnt(6) never blocks here (no exports) and marks the hand-written waits
+      // for that tool. Wave-uniform.
+      if (newp && fill_pending) asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"((NSTORE + (EXCENV_FAULT & 1)) < 63 ? (NSTORE + (EXCENV_FAULT & 1)) : 63) : "memory");
+      if (newp) {
+        fill_pending = false;
+        pc_j = j;
+        last_mask = 0u;
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        const uint32_t q = (uint32_t)j + aem_ph[v];
-        w[v] = (int32_t)(q / (uint32_t)NP);
-        pos[v] = q % (uint32_t)NP;
-        opens = opens || (pos[v] == 0 && rs == 0);
+        for (int v = 0; v < V; ++v) {
+          const uint32_t q = (uint32_t)j + aem_ph[v];
+          pc_w[v] = (int32_t)(q / (uint32_t)NP);
+          const unsigned pos = q % (uint32_t)NP;
+          pc_off[v] = pos * 16u;
+          // the last piece of a window that has a successor not yet requested (w_hi: once per window, whatever the clamped tail of
+          // the trajectory repeats)
+          if (pos == NP - 1 && pc_w[v] + 1 > w_hi[v] && (pc_w[v] + 1) * NP - (int32_t)aem_ph[v] < n_pieces) last_mask |= 1u << v;
+        }
       }
-      // first row of a window (of any slot) that was requested one row earlier: everything but the trajectory stores issued since
-      // must be back (vmcnt retires in issue order: with exactly NSTORE vector-memory instructions behind the fill, vmcnt(NSTORE)
-      // waits for the fill and for nothing younger — fills of other slots issued behind it only make the wait stricter; FEWER than
-      // NSTORE behind it and the wait would prove nothing — tools/isa_guards.py counts them on every path of the built code).
-      // expcnt(6) never blocks here (no exports) and marks the hand-written waits for that tool. Wave-uniform.
-      if (opens) asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"((NSTORE + (EXCENV_FAULT & 1)) < 63 ? (NSTORE + (EXCENV_FAULT & 1)) : 63) : "memory");
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         T rr[A];
-        const unsigned off = pos[v] * 16u + rs * (unsigned)(A * sizeof(T));
+        const unsigned off = pc_off[v] + rs * (unsigned)(A * sizeof(T));
         load_row<T, A>(reinterpret_cast<const T*>(excenv_smem + wave_off + (unsigned)(v * NP) * AEM_BLOCK_BYTES + rd_lane + off), rr);
 #pragma unroll
         for (int q = 0; q < A; ++q) dst[q][v] = rr[q];
       }
       // last row of a slot's window, requested for the last time (with sub-steps a row is requested once as the row after the current
       // one and then once per further sub-step of its own action step; subn is the sub-step the requested row will serve): the
-      // window's LDS is dead once these reads have returned -> request the slot's next window into it. w_hi: once per window,
-      // whatever the clamped tail of the trajectory repeats.
-      bool drained = false;
+      // window's LDS is dead once these reads have returned -> request the slot's next window into it.
+      if (last_mask != 0u && rs == SP - 1 && subn == ka.substeps - 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        if (pos[v] == NP - 1 && rs == SP - 1 && subn == ka.substeps - 1 && w[v] + 1 > w_hi[v] &&
-            (w[v] + 1) * NP - (int32_t)aem_ph[v] < n_pieces) {
-          if (!drained) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          drained = true;
-          dma_window(v, w[v] + 1);
-          w_hi[v] = w[v] + 1;
+        for (int v = 0; v < V; ++v) {
+          if ((last_mask >> v) & 1u) {
+            dma_window(v, pc_w[v] + 1);
+            w_hi[v] = pc_w[v] + 1;
+          }
         }
+        last_mask = 0u;
+        fill_pending = true;
       }
     } else {
 #pragma unroll

@@ -131,11 +131,13 @@ def successors(insns, at, i):
 def _leads_to_marked_wait(insns, i):
     """From instruction i, falling through scalar instructions (compares, further conditional branches of an `a && b && c` chain),
     is a hand-written (expcnt-marked) vmcnt wait the first thing reached?"""
-    for j in range(i, min(i + 24, len(insns))):
+    for j in range(i, min(i + 32, len(insns))):
         x = insns[j]
         if x.op == "s_waitcnt":
             w = waitcnt(x)
             return "vmcnt" in w and w.get("expcnt") == 6
+        if x.op.startswith(("v_readlane", "v_writelane", "v_readfirstlane")):
+            continue  # scalar state kept in a vector register's lanes (SGPR spills of the big instantiations): still scalar bookkeeping
         if not x.op.startswith("s_") or x.op.startswith(("s_branch", "s_endpgm", "s_barrier", "s_load", "s_buffer")):
             return False
     return False
