@@ -955,68 +955,68 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
       }
     }
   };
-  int32_t pc_j = -1, pc_w[V];       // the piece the cached bookkeeping belongs to; its window per slot (all wave-uniform)
-  unsigned pc_off[V];               // byte offset of that piece inside the slot's window
-  uint32_t last_mask = 0u;          // slots whose cached piece is the last of a window with a successor to request
-  bool fill_pending = false;        // a window was requested and no counted wait has run since
-#pragma unroll
-  for (int v = 0; v < V; ++v) {
-    pc_w[v] = 0;
-    pc_off[v] = 0u;
-  }
+  int32_t pc_j = -1;                       // the piece held in pc_reg (wave-uniform)
+  T pc_reg[AEM ? V : 1][AEM ? VW : 1];     // a slot's current 16-byte piece: SP rows of A values
+  bool fill_pending = false;               // a window was requested and no counted wait has run since
   auto load_action = [&](int64_t krow, T (&dst)[A][V]) __attribute__((always_inline)) {
     if constexpr (AEM) {
-      // Bookkeeping once per PIECE (SP rows), not per row (round 5: per row and slot it was ~110 scalar instructions per wave-step —
-      // more issue slots than the fluid tank's whole step; the waves of these kernels are bound by how many instructions of any
-      // kind they issue): which window and which position a slot's piece has, and whether it is the last piece of its window.
+      // Once per PIECE (SP rows), not per row (round 5, second half): the slot's 16-byte piece is read from its LDS window into
+      // registers (one ds_read_b128), the rows are picked out of the registers, and a window whose LAST piece has just been read is
+      // re-requested right away — its fill has SP rows instead of one to land, no LDS read of the wave sits behind a fill in flight
+      // for SP rows, and the bookkeeping (which window, which position, last piece or not: ~110 scalar instructions per wave-step
+      // when it ran per row and slot) runs once per piece. Measured: neutral to -2 % against the row-wise form on every workload
+      // (same buffers) — neither the bookkeeping, nor reads queued behind a fill, nor the fill's slack is what the small models lose
+      // with row-major actions (DESIGN.md §4.1b has the list of what was ruled out). Kept for what it removes.
       const uint32_t kr = (uint32_t)krow;              // 0 <= krow < K < 2^23
       const int32_t j = (int32_t)(kr / (uint32_t)SP);  // the row's piece of its environment's row
       const unsigned rs = kr % (uint32_t)SP;           // the row inside that piece
       const bool newp = j != pc_j;
-      // first row of a piece after a fill was requested (one row earlier, behind the last row of the piece before): everything but
-      // the trajectory stores issued since must be back (vmcnt retires in issue order: with exactly NSTORE vector-memory
-      // instructions behind the fill, vmcnt(NSTORE) waits for the fill and for nothing younger — fills of other slots issued
-      // behind it only make the wait stricter; FEWER than NSTORE behind it and the wait would prove nothing — tools/isa_guards.py
-      // counts them on every path of the built code). expcnt(6) never blocks here (no exports) and marks the hand-written waits
-      // for that tool. Wave-uniform.
+      // first piece after a fill was requested (at least one row, i.e. one saved row's stores, earlier): everything but the
+      // trajectory stores issued since must be back (vmcnt retires in issue order: with at least NSTORE vector-memory instructions
+      // behind the fill, vmcnt(NSTORE) waits for the fill and for nothing it need not — fills of other slots issued behind it only
+      // make the wait stricter; FEWER than NSTORE behind it and the wait would prove nothing — tools/isa_guards.py counts them on
+      // every path of the built code). expcnt(6) never blocks here (no exports) and marks the hand-written waits for that tool.
+      // Wave-uniform.
       if (newp && fill_pending) asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"((NSTORE + (EXCENV_FAULT & 1)) < 63 ? (NSTORE + (EXCENV_FAULT & 1)) : 63) : "memory");
       if (newp) {
         fill_pending = false;
         pc_j = j;
-        last_mask = 0u;
+        uint32_t last_mask = 0u;  // slots whose piece is the last of a window with a successor not yet requested
+        int32_t w[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           const uint32_t q = (uint32_t)j + aem_ph[v];
-          pc_w[v] = (int32_t)(q / (uint32_t)NP);
+          w[v] = (int32_t)(q / (uint32_t)NP);
           const unsigned pos = q % (uint32_t)NP;
-          pc_off[v] = pos * 16u;
-          // the last piece of a window that has a successor not yet requested (w_hi: once per window, whatever the clamped tail of
-          // the trajectory repeats)
-          if (pos == NP - 1 && pc_w[v] + 1 > w_hi[v] && (pc_w[v] + 1) * NP - (int32_t)aem_ph[v] < n_pieces) last_mask |= 1u << v;
+          load_v<T, VW>(reinterpret_cast<const T*>(excenv_smem + wave_off + (unsigned)(v * NP) * AEM_BLOCK_BYTES + rd_lane + pos * 16u), pc_reg[v]);
+          // (w_hi: once per window, whatever the clamped tail of the trajectory repeats)
+          if (pos == NP - 1 && w[v] + 1 > w_hi[v] && (w[v] + 1) * NP - (int32_t)aem_ph[v] < n_pieces) last_mask |= 1u << v;
+        }
+        if (last_mask != 0u) {  // those windows' LDS is dead once the reads above have returned -> request their successors into it
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            if ((last_mask >> v) & 1u) {
+              dma_window(v, w[v] + 1);
+              w_hi[v] = w[v] + 1;
+            }
+          }
+          fill_pending = true;
         }
       }
+      // the row out of the registers (rs is wave-uniform: SP - 1 selects per value)
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        T rr[A];
-        const unsigned off = pc_off[v] + rs * (unsigned)(A * sizeof(T));
-        load_row<T, A>(reinterpret_cast<const T*>(excenv_smem + wave_off + (unsigned)(v * NP) * AEM_BLOCK_BYTES + rd_lane + off), rr);
 #pragma unroll
-        for (int q = 0; q < A; ++q) dst[q][v] = rr[q];
-      }
-      // last row of a slot's window, requested for the last time (with sub-steps a row is requested once as the row after the current
-      // one and then once per further sub-step of its own action step; subn is the sub-step the requested row will serve): the
-      // window's LDS is dead once these reads have returned -> request the slot's next window into it.
-      if (last_mask != 0u && rs == SP - 1 && subn == ka.substeps - 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int q = 0; q < A; ++q) {
+          T val = pc_reg[v][q];
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-          if ((last_mask >> v) & 1u) {
-            dma_window(v, pc_w[v] + 1);
-            w_hi[v] = pc_w[v] + 1;
+          for (int r = 1; r < SP; ++r) {
+            const T alt = pc_reg[v][r * A + q];  // (a value, not an lvalue: a ternary between two lvalues becomes a pointer select -> scratch)
+            val = (rs == (unsigned)r) ? alt : val;
           }
+          dst[q][v] = val;
         }
-        last_mask = 0u;
-        fill_pending = true;
       }
     } else {
 #pragma unroll
@@ -1054,6 +1054,14 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once per trajectory (the initial state has arrived as well)
   }
   load_action(0, a0);
+  if constexpr (AEM) {
+    // A slot whose first window holds a single piece has re-requested it already, and the loop's first load_action follows without a
+    // saved row in between: nothing would stand behind that fill for the counted wait to count (found by tools/isa_guards.py on the
+    // piece-wise form; the row-wise form of rounds 4 - 5 had the same hole for one-row pieces — PMSM fp64 — and an action pointer that
+    // is 16- but not 64-byte aligned). Once per trajectory: wait for it outright.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fill_pending = false;
+  }
   // look-up models keep the single-step loop: twice the (large) look-up code does not fit the instruction cache
   constexpr bool PINGPONG = !M::HAS_LUT && ((SOLVER == EXCENV_EULER) ? (EXCENV_PINGPONG & 1) : (EXCENV_PINGPONG & 2)) != 0;
   if constexpr (PINGPONG) {

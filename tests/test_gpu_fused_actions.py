@@ -165,3 +165,36 @@ def test_fused_row_major_actions_with_control_columns(env_name, control, dtype):
         col = got[0][:, :, O - len(control) + j]
         want_col = torch.as_tensor(2 * (refs[n] - lo) / (hi - lo) - 1, device=env.device)[:, None].expand_as(col)
         assert torch.allclose(col, want_col, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("env_name,dtype,K", [("pmsm", torch.float64, 40), ("pmsm", torch.float32, 40), ("fluid_tank", torch.float32, 64),
+                                              ("pendulum", torch.float64, 48), ("mass_spring_damper", torch.float32, 16)])
+@pytest.mark.parametrize("offset_bytes", [16, 32, 48])
+def test_fused_row_major_actions_from_a_pointer_inside_a_sector(env_name, dtype, K, offset_bytes):
+    """The actions tensor starts 16 / 32 / 48 bytes into a 64-byte sector (a slice of a larger allocation): the first window of an
+    environment's row then holds three, two or ONE piece. The single-piece case re-requests the window in the kernel's prologue, with no
+    saved row between that fill and the loop's first read — tools/isa_guards.py found that nothing stood behind the fill for the counted
+    wait to count (round 5, second half; the row-wise form of rounds 4 - 5 had the hole for one-row pieces, i.e. PMSM fp64). Same bits as
+    the lane-major call, repeatedly (a fill that has not landed would show as stale LDS in the rows of the second window)."""
+    B = 4096
+    env, props, keep, spec = make_env(env_name, B, dtype, solver="euler")
+    env.launch_opts = _native.launch_opts(envs_per_lane=_vmax(dtype))
+    st = random_state(env_name, B, NP_DTYPE[dtype], spec, seed=71)
+    A = env.action_dim
+    n = B * K * A
+    isz = 4 if dtype is torch.float32 else 8
+    whole = torch.zeros(n + 64, dtype=dtype, device=env.device)
+    skip = ((-whole.data_ptr()) % 64 + offset_bytes) // isz
+    plain = whole[skip:skip + n].view(B, K, A)
+    assert plain.data_ptr() % 64 == offset_bytes
+    plain.copy_(torch.as_tensor(np.random.default_rng(72).uniform(-1, 1, (B, K, A)).astype(NP_DTYPE[dtype]), device=env.device))
+    lane = env.new_actions_buffer(K)
+    lane.copy_(plain)
+    assert _fuses(env, plain, K, env.launch_opts)
+    want = env.vmap_sim_ahead(to_state(env, st), lane, env.tau, env.tau)
+    for _ in range(5):
+        whole[:skip].fill_(float("nan"))  # what lies in front of the first row is never used
+        got = env.vmap_sim_ahead(to_state(env, st), plain, env.tau, env.tau)
+        torch.cuda.synchronize()
+        assert _native.last_launch() == "sim_ahead_kernel (row-major actions fused)"
+        _same(env, got, want)
