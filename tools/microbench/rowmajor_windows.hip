@@ -85,6 +85,10 @@ template <int W> static float run(const float* act, float* out, int64_t B, int K
 int main(int argc, char** argv) {
   const int64_t B = (int64_t)1 << (argc > 1 ? std::atoi(argv[1]) : 22);
   const int K = argc > 2 ? std::atoi(argv[2]) : 128;  // rows of K * 4 bytes: a multiple of 256 keeps every window aligned
+  if (K <= 0 || K % 32 != 0) {  // the window loops assume whole windows per row (and never read or write past a row)
+    std::printf("K must be a positive multiple of 32 (rows of whole 128-byte windows)\n");
+    return 2;
+  }
   float *act, *out;
   CK(hipMalloc(&act, sizeof(float) * B * K));
   CK(hipMalloc(&out, sizeof(float) * B * K * NS));
