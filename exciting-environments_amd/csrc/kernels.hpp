@@ -461,9 +461,9 @@ __global__ void __launch_bounds__(BLOCK) step_kernel(const StepArgs<T, M> ka) {
 // environment-slot i * 64 / NP + t / NP and the hardware puts it at M0 + 16 t — the window of an environment is contiguous in
 // LDS as in memory, one 64-byte request per environment and window). Every wave owns V * NP blocks of 1 KiB (+ 16 bytes each:
 // bank skew for the readers) and fetches only the rows of its own lanes' environments: no barrier, every wave on its own.
-// Single-buffered: the window is re-filled right after the read of its last row (the row is read one solver step before it is
-// used, so the fill has a step to land; the counted s_waitcnt in front of the first read of a window leaves that step's
-// trajectory stores in flight).
+// Single-buffered: a slot's 16-byte piece (SP rows) is read into registers once per piece, and the window is re-filled right after
+// the read of its LAST piece (round 5; rounds 4 - 5 read a row per step and re-filled after the last row), so the fill has SP rows to
+// land; the counted s_waitcnt in front of the first piece read behind a fill leaves the last saved row's trajectory stores in flight.
 template <typename T, int V> constexpr bool aem_shape_ok() { return V * (int)sizeof(T) == 16; }
 #ifndef EXCENV_AEM_NP
 #define EXCENV_AEM_NP 4  // 16-byte pieces per window (64 bytes; V * NP KiB of LDS per wave)
