@@ -28,6 +28,12 @@ __device__ __forceinline__ __attribute__((nodebug)) float xabs(float a) { return
 __device__ __forceinline__ __attribute__((nodebug)) double xabs(double a) { return __builtin_fabs(a); }
 __device__ __forceinline__ __attribute__((nodebug)) float xsqrt(float a) { return __builtin_sqrtf(a); }  // correctly rounded (hipcc default)
 __device__ __forceinline__ __attribute__((nodebug)) double xsqrt(double a) { return __builtin_sqrt(a); }
+// sqrt(s) > 1 without the square root (the PMSM flags |i_dq| > 1, pmsm_env.py:972-983, per environment and saved row). With a
+// correctly rounded square root the two are the same predicate for EVERY s: sqrt(s) rounds above 1 iff sqrt(s) > 1 + ulp/2 (the tie
+// goes to the even neighbour, 1), i.e. s > 1 + ulp + ulp^2/4, i.e. s >= 1 + 2 ulp — as a value of the type: s > nextafter(1). NaN: false
+// both ways; inf: true both ways. Checked exhaustively over the 2^21 values around 1 in both precisions (tests/test_oracle_golden.py).
+__device__ __forceinline__ bool sqrt_exceeds_one(float s) { return s > 1.00000011920928955078125f; }   // 1 + 2^-23
+__device__ __forceinline__ bool sqrt_exceeds_one(double s) { return s > 1.0000000000000002220446049250313; }  // 1 + 2^-52
 // (the library's bit-serial remainder loop: out of line, see sincos_lib below — taken only for |x| / 2 pi >= 2^22, NaN, inf)
 __device__ __attribute__((noinline)) float xfmod_slow(float a, float b) { return fmodf(a, b); }
 __device__ __attribute__((noinline)) double xfmod_slow(double a, double b) { return fmod(a, b); }

@@ -305,7 +305,7 @@ __device__ __forceinline__ void gym_outputs(const T (&st)[M::S], const T (&ob)[M
   if (reward != nullptr) *reward = rew;
   if constexpr (M::IS_PMSM) {  // pmsm_env.py:972-983: |i_dq_norm| > 1, terminated == truncated
     const T nd = normalize(st[3], c.smin[3], c.smax[3]), nq = normalize(st[4], c.smin[4], c.smax[4]);
-    const uint8_t t = xsqrt(nd * nd + nq * nq) > T(1);
+    const uint8_t t = sqrt_exceeds_one(nd * nd + nq * nq);  // == sqrt(.) > 1, bit for bit (devmath.hpp)
     if (truncated != nullptr) truncated[0] = t;
     if (terminated != nullptr) *terminated = t;
   } else if constexpr (M::ID == EXCENV_FLUID_TANK) {  // fluid_tank_env.py:325-333: constants
@@ -852,7 +852,7 @@ __global__ void __launch_bounds__(NT) EXCENV_SIM_KERNEL_ATTR sim_ahead_kernel(co
       for (int v = 0; v < V; ++v) {
         rew[v] = pmsm_reward<M, T>(sv[v], c, has_id, g_id[v], has_iq, g_iq[v], has_tq, g_tq[v]);
         const T nd = normalize(sv[v][3], c.smin[3], c.smax[3]), nq = normalize(sv[v][4], c.smin[4], c.smax[4]);
-        fl[v] = xsqrt(nd * nd + nq * nq) > T(1);  // pmsm_env.py:972-983: terminated == truncated
+        fl[v] = sqrt_exceeds_one(nd * nd + nq * nq);  // pmsm_env.py:972-983: sqrt(.) > 1 (devmath.hpp), terminated == truncated
       }
       const int64_t e0 = blk0 + lane_env;
       store_flags<V>(ka.truncated + n * ka.t_sk + e0, fl);

@@ -4,6 +4,8 @@ Mirrors the reference's test_step_results (e.g. tests/envs/pendulum/test_pendulu
 tests/envs/pmsm/test_pmsm.py:150-174): state from stored_observations[0], explicit Euler, fp64,
 10 000 (PMSM 1 000) single-env steps, jnp.allclose(rtol=1e-16 | 1e-8, atol=1e-8).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -117,3 +119,23 @@ def test_layouts_agree(golden):
     for j in range(7):
         assert np.array_equal(straj_lm[j].T, straj[j])
         assert np.array_equal(last_lm[j], last[j])
+
+
+def test_sqrt_free_form_of_the_pmsm_flag_predicate():
+    """devmath.hpp sqrt_exceeds_one: the PMSM kernels test `s > nextafter(1)` where the reference (and the oracle) test `sqrt(s) > 1`
+    (pmsm_env.py:972-983). With a correctly rounded square root the two are the same predicate for every s — exhaustively over the
+    2^21 representable values around 1 in both precisions, over random values and the special ones."""
+    import re
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "exciting-environments_amd", "csrc", "devmath.hpp")).read()
+    thr = dict(re.findall(r"sqrt_exceeds_one\((float|double) s\) \{ return s > ([0-9.]+)f?;", src))
+    for np_t, bits_t, key in ((np.float32, np.uint32, "float"), (np.float64, np.uint64, "double")):
+        one = np_t(1.0)
+        nxt = np.nextafter(one, np_t(2.0))
+        assert np_t(float(thr[key])) == nxt, (key, thr[key])  # the constant in the source is exactly nextafter(1)
+        b1 = int(one.view(bits_t))
+        x = np.arange(b1 - (1 << 20), b1 + (1 << 20), dtype=bits_t).view(np_t)
+        assert ((np.sqrt(x) > one) == (x > nxt)).all()
+        y = np.concatenate([np.random.default_rng(3).uniform(0, 4, 2_000_000).astype(np_t),
+                            np.array([0.0, np.inf, np.nan, np.finfo(np_t).tiny, np.finfo(np_t).max, 1.0], dtype=np_t)])
+        assert ((np.sqrt(y) > one) == (y > nxt)).all()
