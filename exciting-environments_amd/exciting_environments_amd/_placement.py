@@ -522,7 +522,10 @@ class TrajectoryPlacement:
                     self.sets.append(self.sets.pop(k))  # most recently used last
                     return ts
             self.sets = [t for t in self.sets if t.key == key][-(self.POOL_SETS - 1):] if self.POOL_SETS > 1 else []
-        if (pooled and want_states and (not env_major or self.QUAD_ENV_MAJOR) and self.mode == "auto" and self.target is None
+        # the arena pair only where something can judge it as a whole: the access-pattern replay (lane-major sets of calls whose
+        # pattern it can replay), or on request for row-major sets (see QUAD_ENV_MAJOR); everything else is searched
+        if (pooled and want_states and ((not env_major and pattern_ctx is not None) or (env_major and self.QUAD_ENV_MAJOR))
+                and self.mode == "auto" and self.target is None
                 and replacing is None and self.POOL_SETS == 2 and not self.sets and key not in self.quad_made
                 and (OW + S) * rows * B * isz >= max(self.PLACED_BYTES, self.QUAD_MIN_SET_BYTES)):
             first = self._ordered_pair(key, B, rows, OW, S, last_e, isz, stream, env_major, pattern_ctx)
