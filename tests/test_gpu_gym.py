@@ -140,6 +140,10 @@ def test_sim_ahead_fused_rew_trunc_term_matches_oracle(env_name, dtype, semantic
     assert torch.equal(obs, obs2)  # asking for the extra outputs does not change the trajectory
     TW = 1 if env_name in ("pmsm", "fluid_tank") else obs.shape[-1]
     assert reward.shape == (B, K, 1) and terminated.shape == (B, K, 1) and truncated.shape == (B, K + 1, TW)
+    if layout == "lane_major":  # ABI 7 (include/excenv.h): reward / terminated [row][B], truncated [row][B][flag] — views of exactly that
+        assert tuple(truncated.stride()) == (TW, B * TW, 1) and tuple(reward.stride())[:2] == (1, B) and tuple(terminated.stride())[:2] == (1, B)
+    else:
+        assert truncated.is_contiguous() and reward.is_contiguous() and terminated.is_contiguous()
     st_np = [getattr(states.physical_state, n).cpu().numpy() for n in env.STATE_FIELDS]
     control = [(n, refs[n]) for n in cs]
     r_ref, tr_ref, te_ref = oracle.rew_trunc_term_ahead(env_name, st_np, props, control=control)
