@@ -67,6 +67,65 @@ __global__ void __launch_bounds__(256) traj(const float* __restrict__ act, float
   }
 }
 
+// The same launch with the product's mechanism for the 64-byte windows: LDS-direct loads (four adjacent lanes fetch the four pieces
+// of one environment's sector, 16 environments per instruction, the hardware puts lane t's 16 bytes at M0 + 16 t), then every lane
+// reads its own window from LDS, one 16-byte piece per four rows. Synchronous like the register form above (fill, wait, use).
+__global__ void __launch_bounds__(256) traj_dma(const float* __restrict__ act, float* __restrict__ out, int64_t B, int K) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+  if (e0 >= B) return;  // B is a multiple of 64 * V here: whole waves
+  const unsigned wave = threadIdx.x / 64u, lane = threadIdx.x % 64u;
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + wave * (V * 4 * 1024));
+  const int64_t wave_e0 = ((int64_t)blockIdx.x * 256 + wave * 64) * V;
+  float s[V] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* src = act + (wave_e0 + (int64_t)(i * 16 + lane / 4) * V + v) * (int64_t)K + k0 + 4 * (lane % 4);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(wave_lds + (unsigned)(v * 4 + i) * 1024u) : "memory", "m0");
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      v4 piece[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v)
+        piece[v] = *reinterpret_cast<const v4*>(smem + wave * (V * 4 * 1024) + (unsigned)(v * 4 + lane / 16) * 1024u + (lane % 16) * 64u + p * 16u);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] = s[v] * 0.5f + piece[v][r];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          v4 o;
+#pragma unroll
+          for (int v = 0; v < V; ++v) o[v] = s[v] + (float)j;
+          __builtin_nontemporal_store(o, reinterpret_cast<v4*>(out + ((int64_t)(k0 + 4 * p + r) * NS + j) * B + e0));
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the windows' LDS is re-filled at the top of the loop
+  }
+}
+static float run_dma(const float* act, float* out, int64_t B, int K, int reps) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  const dim3 grid((unsigned)((B / V + 255) / 256)), block(256);
+  const size_t lds = 4 * V * 4 * 1024;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(traj_dma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(traj_dma, grid, block, lds, 0, act, out, B, K);
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(traj_dma, grid, block, lds, 0, act, out, B, K);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
 template <int W> static float run(const float* act, float* out, int64_t B, int K, int reps) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
@@ -85,7 +144,7 @@ template <int W> static float run(const float* act, float* out, int64_t B, int K
 int main(int argc, char** argv) {
   const int64_t B = (int64_t)1 << (argc > 1 ? std::atoi(argv[1]) : 22);
   const int K = argc > 2 ? std::atoi(argv[2]) : 128;  // rows of K * 4 bytes: a multiple of 256 keeps every window aligned
-  if (K <= 0 || K % 32 != 0) {  // the window loops assume whole windows per row (and never read or write past a row)
+  if (B < 1024 || K <= 0 || K % 32 != 0) {  // the window loops assume whole windows per row (and never read or write past a row)
     std::printf("K must be a positive multiple of 32 (rows of whole 128-byte windows)\n");
     return 2;
   }
@@ -98,8 +157,9 @@ int main(int argc, char** argv) {
               bytes / 1e9, 4 * (1 + NS), 100.0 / (1 + NS));
   for (int round = 0; round < 2; ++round) {
     const float t0 = run<0>(act, out, B, K, 10), t32 = run<32>(act, out, B, K, 10), t64 = run<64>(act, out, B, K, 10), t128 = run<128>(act, out, B, K, 10);
-    std::printf("round %d  lane-major %.3f ms (%.0f GB/s) | 32-byte windows %.3f (%.2f x) | 64-byte %.3f (%.2f x) | 128-byte %.3f (%.2f x)\n", round, t0,
-                bytes / t0 / 1e6, t32, t32 / t0, t64, t64 / t0, t128, t128 / t0);
+    const float td = (B % (64 * V) == 0) ? run_dma(act, out, B, K, 10) : 0.f;
+    std::printf("round %d  lane-major %.3f ms (%.0f GB/s) | 32-byte windows %.3f (%.2f x) | 64-byte %.3f (%.2f x) | 128-byte %.3f (%.2f x) | "
+                "64-byte windows by LDS-direct loads %.3f (%.2f x)\n", round, t0, bytes / t0 / 1e6, t32, t32 / t0, t64, t64 / t0, t128, t128 / t0, td, td / t0);
   }
   CK(hipFree(act));
   CK(hipFree(out));
