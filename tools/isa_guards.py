@@ -9,8 +9,12 @@ built library (or of one object file) is disassembled and three properties are c
         instructions were issued behind it: fewer (a store the compiler merged or skipped on some path) and the wait returns while
         the fill may still be in flight -> stale LDS, timing-dependent. More than N is safe but waits for trajectory stores.
         Check: on every path from a fill to the first `ds_read*`, a vmcnt wait with N <= (vector-memory instructions since the fill)
-        is passed first. The skip edge of a wave-uniform `if (first row of the window) wait;` is not followed (the window phase is
-        source-level logic, covered by the bit-equality tests; what this guard covers is the COUNT).
+        is passed first. The skip edge of a wave-uniform `if (first piece read behind a fill) wait;` is not followed (which step
+        that is is source-level logic, covered by the bit-equality tests; what this guard covers is the COUNT) — but a fill that
+        reaches such a wait with NOTHING behind it is reported: that is how the prologue hole of round 5 was found (a window
+        re-requested before the loop, the loop's first read following without a saved row in between). Scalar state the compiler
+        parks in vector lanes (`v_readlane` / `v_writelane`, the big instantiations run out of SGPRs) counts as scalar bookkeeping
+        when the tool looks for the wait behind a branch.
   bar   gfx950 backs `s_barrier` off instead of waiting for the wave's outstanding LDS writes, and the compiler adds no wait in
         front of the raw builtin: every `s_barrier` must be reached with no `ds_write*` outstanding, i.e. behind an
         `s_waitcnt lgkmcnt(0)` on every path (forward dataflow over the kernel's control-flow graph).
